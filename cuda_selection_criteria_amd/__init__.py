@@ -1,0 +1,15 @@
+"""MI355X-native all-pairs SuperMinHash/HLL sketch selection (drop-in for the hot path of
+sanhue903/CUDA_Selection_Criteria: `selection` / `time_smh_cuda`).
+
+Python here is plumbing only (device memory via torch, torch.distributed for the multi-GPU gather,
+ctypes bindings); the product is csrc/ (HIP kernels + C ABI in include/selection_hip.h, C++ host code).
+"""
+from ._lib import (ALGO_AUTO, ALGO_SIG, ALGO_STREAM, BANDING_CPU, BANDING_CUDA, FP_FMA, FP_STRICT,  # noqa: F401
+                   MODE_CB_SMH, MODE_SMH, SelhipError, hip_lib, host_lib)
+from .selection import (PAIR_DTYPE, Selector, banding, format_lines, load_dataset, select_from_filelist,  # noqa: F401
+                        sort_by_card)
+from .synth import SYNTH_CONFIGS, SynthConfig, synth_device, synth_host  # noqa: F401
+
+__all__ = ["Selector", "banding", "select_from_filelist", "load_dataset", "sort_by_card", "format_lines",
+           "SynthConfig", "SYNTH_CONFIGS", "synth_device", "synth_host", "hip_lib", "host_lib", "SelhipError",
+           "MODE_SMH", "MODE_CB_SMH", "ALGO_AUTO", "ALGO_STREAM", "ALGO_SIG", "FP_FMA", "FP_STRICT", "PAIR_DTYPE"]

@@ -1,0 +1,115 @@
+// selection_main.cpp -- `selection`: drop-in for the reference's GPU selection driver
+// (src/selection_cuda.cpp:59-189; README.md:60-66 documents it as `selection -l -h -a -b`),
+// producing the OUTPUT of the reference's CPU program src/selection.cpp:228-300 (criterion smh_a):
+// lines "fn1 fn2 <jaccard %f>" in rank order.
+//
+//   -l <file>   list of genome paths; <path>.hll and <path>.smh<m> must exist (written by build_sketch)
+//   -h <tau>    similarity threshold (float, std::stof like selection.cpp:103)
+//   -a <bytes>  auxiliary memory per genome; m = bytes/8 SuperMinHash buckets (selection.cpp:231)
+//   -b <n>      accepted for CLI compatibility (CUDA block size in the reference); ignored
+//   -c <crit>   accepted; only smh_a is implemented by this path (selection_cuda.cpp:64 ignores it too)
+//   -t <n>      host threads for loading sketches (selection.cpp:97)
+//   -g <n>      number of GPUs to shard the pair space over (default 1)
+//   -n          no CB pruning ("smh_a" mode of experiments/src/time_smh.cpp:229-257)
+//   -A <algo>   stage-1 algorithm: auto | stream | sig
+//   -F <0|1>    estimator flavour: 1 = FMA (reference Makefile build on FMA hosts, default), 0 = strict
+//   -x          usage
+#include <unistd.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <iostream>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../../include/selection_hip.h"
+#include "../../../include/selection_host.h"
+
+int main(int argc, char* argv[]) {
+    std::string list_file = "";
+    float threshold = 0.9f;              // selection_cuda.cpp:62
+    int aux_bytes = 256;                 // selection_cuda.cpp:63
+    std::string criterion = "smh_a";
+    int threads = 8, n_gpus = 1, mode = SELHIP_MODE_CB_SMH, algo = SELHIP_ALGO_AUTO, fp_mode = SELHIP_FP_FMA;
+    int c;
+    while ((c = getopt(argc, argv, "xl:b:a:h:c:t:g:nA:F:")) != -1) {
+        switch (c) {
+            case 'x': std::cout << "Usage: -l -h -a -b [-c smh_a] [-t threads] [-g gpus] [-n] [-A auto|stream|sig] [-F 0|1]\n"; return 0;
+            case 'l': list_file = optarg; break;
+            case 'b': break;
+            case 'a': aux_bytes = std::stoi(optarg); break;
+            case 'h': threshold = std::stof(optarg); break;
+            case 'c': criterion = optarg; break;
+            case 't': threads = std::stoi(optarg); break;
+            case 'g': n_gpus = std::stoi(optarg); break;
+            case 'n': mode = SELHIP_MODE_SMH; break;
+            case 'A': algo = !strcmp(optarg, "stream") ? SELHIP_ALGO_STREAM : !strcmp(optarg, "sig") ? SELHIP_ALGO_SIG : SELHIP_ALGO_AUTO; break;
+            case 'F': fp_mode = std::stoi(optarg) ? SELHIP_FP_FMA : SELHIP_FP_STRICT; break;
+            default: break;
+        }
+    }
+    if (criterion != "smh_a") {
+        std::cout << "Option -c invalid. This program implements the smh_a criterion.\n";
+        return 0;
+    }
+    if (list_file.empty()) { std::cerr << "No input file provided\n"; exit(-1); }   // selection.cpp:40-44
+    const unsigned m = (unsigned)aux_bytes / 8;
+
+    selhost_dataset* ds = nullptr;
+    int rc = selhost_dataset_load(&ds, list_file.c_str(), m, 0, fp_mode, threads);
+    if (rc) { std::cerr << selhost_last_error() << "\n"; exit(-1); }
+    const int64_t n = selhost_dataset_size(ds);
+
+    int n_rows = 1, n_bands = 1;
+    selhost_banding(m, threshold, SELHOST_BANDING_CPU, &n_rows, &n_bands);
+
+    const int avail = selhip_device_count();
+    if (avail <= 0) { std::cerr << "selection: no MI355X (gfx950) device available: " << selhip_last_error(nullptr) << "\n"; return 3; }
+    if (n_gpus < 1) n_gpus = 1;
+    if (n_gpus > avail) n_gpus = avail;
+
+    std::vector<int64_t> bounds((size_t)n_gpus + 1);
+    // equal-pair-count row shards; the CB cut-off only shortens rows, the triangular estimate is used here
+    selhost_shard_rows(n, nullptr, 0, n_gpus, bounds.data());
+
+    std::vector<std::vector<selhip_pair_t>> parts((size_t)n_gpus);
+    std::vector<int> status((size_t)n_gpus, 0);
+    std::vector<std::string> errs((size_t)n_gpus);
+    auto worker = [&](int g) {
+        selhip_ctx* ctx = nullptr;
+        int r = selhip_ctx_create(&ctx, g);
+        if (r) { status[(size_t)g] = r; errs[(size_t)g] = selhip_last_error(nullptr); return; }
+        selhip_ctx_set_fp_mode(ctx, fp_mode);
+        r = selhip_ctx_upload(ctx, selhost_dataset_hll(ds), selhost_dataset_aux(ds), selhost_dataset_cards(ds), n, (int)m, 14);
+        if (!r) r = selhip_ctx_run(ctx, mode, algo, threshold, n_rows, n_bands, bounds[(size_t)g], bounds[(size_t)g + 1]);
+        if (!r) {
+            int64_t cnt = selhip_ctx_result_count(ctx);
+            parts[(size_t)g].resize((size_t)cnt);
+            r = selhip_ctx_fetch(ctx, parts[(size_t)g].data(), cnt);
+        }
+        if (r) { status[(size_t)g] = r; errs[(size_t)g] = selhip_last_error(ctx); }
+        selhip_ctx_destroy(ctx);
+    };
+    if (n_gpus == 1) worker(0);
+    else {
+        std::vector<std::thread> th;
+        for (int g = 0; g < n_gpus; ++g) th.emplace_back(worker, g);
+        for (auto& t : th) t.join();
+    }
+    for (int g = 0; g < n_gpus; ++g)
+        if (status[(size_t)g]) { std::cerr << "selection: GPU " << g << ": " << errs[(size_t)g] << "\n"; return 4; }
+
+    // shards are contiguous row ranges and each part is sorted by (i,k): concatenation = print order
+    std::string out;
+    char line[8192];
+    for (int g = 0; g < n_gpus; ++g)
+        for (const selhip_pair_t& pr : parts[(size_t)g]) {
+            int w = selhost_format_line(selhost_dataset_name(ds, pr.i), selhost_dataset_name(ds, pr.k), pr.jaccard, line, sizeof line);
+            if (w > 0) out.append(line, (size_t)w);
+        }
+    std::cout << out;
+    selhost_dataset_free(ds);
+    return 0;
+}

@@ -1,0 +1,204 @@
+"""Host-side mirror of the reference's GPU selection driver (src/selection_cuda.cpp:59-189) on top of
+the C ABI.  Same steps, same names: load_file_list -> read sketches -> report() -> sort by cardinality
+-> banding -> flatten -> upload -> launch -> copy back -> print; all the work happens in
+libselhost.so (C++) and libselhip.so (HIP)."""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import _lib
+from ._lib import (ALGO_AUTO, BANDING_CPU, FP_FMA, MODE_CB_SMH, Pair, check, hip_lib, host_lib)
+
+# layout of selhip_pair_t {int32 i, k; double jaccard}
+PAIR_DTYPE = np.dtype([("i", "<i4"), ("k", "<i4"), ("jaccard", "<f8")], align=True)
+assert PAIR_DTYPE.itemsize == C.sizeof(Pair) == 16
+
+
+def banding(m: int, tau: float, variant: int = BANDING_CPU) -> Tuple[int, int]:
+    """(n_rows, n_bands) of src/selection.cpp:258-267 (CPU variant) or selection_cuda.cpp:119-128."""
+    r, b = C.c_int(), C.c_int()
+    host_lib().selhost_banding(m, np.float32(tau), variant, C.byref(r), C.byref(b))
+    return r.value, b.value
+
+
+def sort_by_card(cards: np.ndarray) -> np.ndarray:
+    """perm[rank] = original index; libstdc++ std::sort with the comparator of selection.cpp:251-256."""
+    cards = np.ascontiguousarray(cards, dtype=np.float64)
+    perm = np.empty(cards.shape[0], dtype=np.int32)
+    rc = host_lib().selhost_sort_by_card(cards.ctypes.data, cards.shape[0], perm.ctypes.data)
+    if rc:
+        raise RuntimeError(host_lib().selhost_last_error().decode())
+    return perm
+
+
+@dataclass
+class Dataset:
+    names: list
+    hll: np.ndarray        # [n, 16384] u8, rank order
+    aux: np.ndarray        # [n, m] u64
+    aux_hll: np.ndarray    # [n, 1 << p_aux] u8 (empty when p_aux == 0)
+    cards: np.ndarray      # [n] f64 ascending
+
+
+def load_dataset(list_file: str, m: int, p_aux: int = 0, fp_mode: int = FP_FMA, threads: int = 8) -> Dataset:
+    """selection_cuda.cpp:90-143: read <name>.hll / <name>.smh<m>, report(), sort, flatten."""
+    h = host_lib()
+    ds = C.c_void_p()
+    rc = h.selhost_dataset_load(C.byref(ds), list_file.encode(), m, p_aux, fp_mode, threads)
+    if rc:
+        raise RuntimeError(f"selhost error {rc}: {h.selhost_last_error().decode()}")
+    try:
+        n = h.selhost_dataset_size(ds)
+        def arr(ptr, shape, dt):
+            count = int(np.prod(shape))
+            if n == 0 or count == 0:
+                return np.zeros(shape, dtype=dt)
+            buf = (C.c_uint8 * (count * np.dtype(dt).itemsize)).from_address(ptr)
+            return np.frombuffer(buf, dtype=dt).reshape(shape).copy()
+        hll = arr(h.selhost_dataset_hll(ds), (n, 16384), np.uint8)
+        aux = arr(h.selhost_dataset_aux(ds), (n, m), np.uint64)
+        aux_hll = arr(h.selhost_dataset_aux_hll(ds), (n, (1 << p_aux) if p_aux else 0), np.uint8)
+        cards = arr(h.selhost_dataset_cards(ds), (n,), np.float64)
+        names = [h.selhost_dataset_name(ds, r).decode() for r in range(n)]
+    finally:
+        h.selhost_dataset_free(ds)
+    return Dataset(names, hll, aux, aux_hll, cards)
+
+
+def format_lines(names: Sequence[str], pairs: np.ndarray) -> str:
+    """'fn1 fn2 <std::to_string(J)>\\n' per selected pair (selection.cpp:288)."""
+    h = host_lib()
+    buf = C.create_string_buffer(16384)
+    out = []
+    for rec in pairs:
+        w = h.selhost_format_line(names[rec["i"]].encode(), names[rec["k"]].encode(), float(rec["jaccard"]), buf, len(buf))
+        if w < 0:
+            raise RuntimeError("line too long")
+        out.append(buf.raw[:w].decode())
+    return "".join(out)
+
+
+class Selector:
+    """One selhip context = one GPU (`selhip_ctx_*`, include/selection_hip.h section 2)."""
+
+    def __init__(self, device: int = 0, fp_mode: int = FP_FMA, stream: Optional[int] = None):
+        self._lib = hip_lib()
+        self._ctx = C.c_void_p()
+        check(self._lib.selhip_ctx_create(C.byref(self._ctx), device))
+        check(self._lib.selhip_ctx_set_fp_mode(self._ctx, fp_mode), self._ctx)
+        if stream is not None:
+            check(self._lib.selhip_ctx_set_stream(self._ctx, C.c_void_p(stream)), self._ctx)
+        self.n = 0
+        self.m = 0
+        self._keep = None
+
+    def close(self):
+        if self._ctx:
+            self._lib.selhip_ctx_destroy(self._ctx)
+            self._ctx = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    # -- sketches ---------------------------------------------------------------------------------
+    def upload(self, hll: np.ndarray, aux: np.ndarray, cards: Optional[np.ndarray] = None, p_hll: int = 14):
+        hll = np.ascontiguousarray(hll, dtype=np.uint8)
+        aux = np.ascontiguousarray(aux, dtype=np.uint64)
+        n, m = aux.shape
+        assert hll.shape == (n, 1 << p_hll), (hll.shape, n, p_hll)
+        cp = None
+        if cards is not None:
+            cards = np.ascontiguousarray(cards, dtype=np.float64)
+            assert cards.shape == (n,)
+            cp = cards.ctypes.data
+        check(self._lib.selhip_ctx_upload(self._ctx, hll.ctypes.data, aux.ctypes.data, cp, n, m, p_hll), self._ctx)
+        self.n, self.m = n, m
+
+    def attach(self, hll_t, aux_t, cards_t=None, p_hll: int = 14):
+        """torch CUDA tensors: hll uint8 [n, 1<<p], aux int64 [n, m] (bit pattern of the u64 buckets),
+        cards float64 [n] ascending or None."""
+        n, m = aux_t.shape
+        assert hll_t.is_cuda and aux_t.is_cuda and hll_t.is_contiguous() and aux_t.is_contiguous()
+        assert tuple(hll_t.shape) == (n, 1 << p_hll) and aux_t.element_size() == 8 and hll_t.element_size() == 1
+        cp = None
+        if cards_t is not None:
+            assert cards_t.is_cuda and cards_t.is_contiguous() and cards_t.element_size() == 8 and cards_t.shape[0] == n
+            cp = cards_t.data_ptr()
+        check(self._lib.selhip_ctx_attach(self._ctx, hll_t.data_ptr(), aux_t.data_ptr(), cp, n, m, p_hll), self._ctx)
+        self._keep = (hll_t, aux_t, cards_t)
+        self.n, self.m = n, m
+
+    def cards(self) -> np.ndarray:
+        out = np.empty(self.n, dtype=np.float64)
+        check(self._lib.selhip_ctx_get_cards(self._ctx, out.ctypes.data), self._ctx)
+        return out
+
+    # -- the hot path -------------------------------------------------------------------------------
+    def run(self, tau: float, mode: int = MODE_CB_SMH, n_rows: Optional[int] = None, n_bands: Optional[int] = None,
+            rows: Optional[Tuple[int, int]] = None, algo: int = ALGO_AUTO, fetch: bool = True):
+        if n_rows is None or n_bands is None:
+            n_rows, n_bands = banding(self.m, tau)
+        rb, re = rows if rows is not None else (0, self.n)
+        check(self._lib.selhip_ctx_run(self._ctx, mode, algo, np.float32(tau), n_rows, n_bands, rb, re), self._ctx)
+        return self.fetch() if fetch else None
+
+    def run_async(self, tau: float, mode: int = MODE_CB_SMH, n_rows: Optional[int] = None, n_bands: Optional[int] = None,
+                  rows: Optional[Tuple[int, int]] = None, algo: int = ALGO_AUTO):
+        if n_rows is None or n_bands is None:
+            n_rows, n_bands = banding(self.m, tau)
+        rb, re = rows if rows is not None else (0, self.n)
+        check(self._lib.selhip_ctx_run_async(self._ctx, mode, algo, np.float32(tau), n_rows, n_bands, rb, re), self._ctx)
+
+    def finish(self):
+        check(self._lib.selhip_ctx_finish(self._ctx), self._ctx)
+
+    def result_count(self) -> int:
+        return int(check(self._lib.selhip_ctx_result_count(self._ctx), self._ctx))
+
+    def fetch(self) -> np.ndarray:
+        cnt = self.result_count()
+        out = np.zeros(cnt, dtype=PAIR_DTYPE)
+        check(self._lib.selhip_ctx_fetch(self._ctx, out.ctypes.data if cnt else None, cnt), self._ctx)
+        return out
+
+    def result_device(self) -> Tuple[int, int]:
+        """(device pointer to the unsorted selhip_pair_t list, count)"""
+        p, cnt = C.c_void_p(), C.c_int64()
+        check(self._lib.selhip_ctx_result_device(self._ctx, C.byref(p), C.byref(cnt)), self._ctx)
+        return (p.value or 0), cnt.value
+
+    def stats(self) -> dict:
+        st = (C.c_int64 * 4)()
+        check(self._lib.selhip_ctx_stats(self._ctx, st), self._ctx)
+        return {"evaluated": st[0], "survivors": st[1], "selected": st[2], "candidates": st[3]}
+
+    def timing(self, enable: bool = True):
+        check(self._lib.selhip_ctx_timing(self._ctx, 1 if enable else 0), self._ctx)
+
+    def kernel_ms(self, name: str) -> float:
+        return float(self._lib.selhip_ctx_kernel_ms(self._ctx, name.encode()))
+
+
+def select_from_filelist(list_file: str, tau: float, aux_bytes: int, mode: int = MODE_CB_SMH, device: int = 0,
+                         fp_mode: int = FP_FMA, algo: int = ALGO_AUTO) -> str:
+    """The whole of selection_cuda.cpp main(): returns the text the CPU reference prints."""
+    m = aux_bytes // 8
+    ds = load_dataset(list_file, m, 0, fp_mode)
+    n_rows, n_bands = banding(m, tau)
+    with Selector(device, fp_mode) as sel:
+        sel.upload(ds.hll, ds.aux, ds.cards)
+        pairs = sel.run(tau, mode, n_rows, n_bands, algo=algo)
+    return format_lines(ds.names, pairs)

@@ -1,0 +1,192 @@
+/*
+ * selection_hip.h -- C ABI of libselhip.so: the MI355X (gfx950) replacement for the reference's GPU
+ * kernel boundary of the all-pairs sketch-selection step.
+ *
+ * What it replaces in sanhue903/CUDA_Selection_Criteria (paths relative to that repository):
+ *   src/selection_kernels_wrapper.hpp:6-45   struct Result, launch_kernel_smh, launch_kernel_CBsmh
+ *   src/selection_kernels.cu:13-177          kernel_smh / kernel_CBsmh and their launchers
+ *   include/criteria_sketch_cuda.cuh:11-65   device CB / smh_a / hll_union_card
+ *   src/selection_cuda.cpp:152-182           the raw cudaMalloc/cudaMemcpy/launch/copy-back sequence
+ *                                            (here: the selhip_ctx_* lifecycle)
+ *
+ * RESULT SEMANTICS are those of the reference's CPU path src/selection.cpp:270-291 (the parity target
+ * named by BASELINE.json), NOT of its CUDA kernels (which use a different HLL estimator, never apply
+ * CB and index out of bounds -- SURVEY.md section 2.3):
+ *   pair (i,k), i<k in ascending-cardinality rank order, is selected iff
+ *     e_k != 0                                   (selection.cpp:281; e = (size_t)cardinality, :275,:280)
+ *     [CB modes]  (double)e_i / (double)e_k >= (double)tau_f            (criteria_sketch.hpp:45-49)
+ *     smh_a: some band of n_rows consecutive u64 buckets is entirely equal   (criteria_sketch.hpp:66-81)
+ *     J = ((double)e_i + (double)e_k - U) / U >= (double)tau_f, U = Ertl-MLE estimate of the register-wise
+ *         max of the two p=14 HyperLogLog sketches                     (hll.h:1188-1210 -> :629-688)
+ *
+ * All functions return 0 on success or a negative SELHIP_E_* code; nothing throws across the ABI.
+ * No HIP, torch or C++ types appear in any signature.  Pointers named d_* are DEVICE pointers owned by
+ * the caller (hipMalloc, or a torch tensor's data_ptr()); h_* are host pointers.
+ */
+#ifndef SELECTION_HIP_H
+#define SELECTION_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SELHIP_OK              0
+#define SELHIP_E_BADARG       -1   /* null pointer, bad size, rows*bands != m, ...                      */
+#define SELHIP_E_HIP          -2   /* a HIP runtime call failed; see selhip_last_error()                */
+#define SELHIP_E_OVERFLOW     -3   /* an output buffer was too small; nothing was lost: counts are exact */
+#define SELHIP_E_NODEVICE     -4   /* no usable gfx950 device                                           */
+#define SELHIP_E_STATE        -5   /* call sequence error (e.g. run before upload)                      */
+
+/* == struct Result of src/selection_kernels_wrapper.hpp:6-9 (same layout: 12 bytes) */
+typedef struct { int32_t x, y; float sim; } selhip_result_t;
+/* == CUDA int2 used for the pair list (wrapper.hpp:16) */
+typedef struct { int32_t x, y; } selhip_int2_t;
+/* full-precision output record of the context API: the CPU path prints J with std::to_string(double) */
+typedef struct { int32_t i, k; double jaccard; } selhip_pair_t;
+
+/* modes, after the two timed regions of experiments/src/time_smh.cpp:229-257 / :261-292 */
+#define SELHIP_MODE_SMH      0     /* "smh_a": every pair i<k (e_k==0 skipped), no CB                    */
+#define SELHIP_MODE_CB_SMH   1     /* "CB+smh_a": = src/selection.cpp:270-291                            */
+
+/* stage-1 algorithm */
+#define SELHIP_ALGO_AUTO     0
+#define SELHIP_ALGO_STREAM   1     /* full m-bucket compare, candidates streamed row-major, query tile in LDS */
+#define SELHIP_ALGO_SIG      2     /* 32-bit band signatures joined all-pairs, exact verify of candidates  */
+
+/* estimator arithmetic flavour (see csrc/ertl_mle.hpp) */
+#define SELHIP_FP_FMA        1     /* = reference built by its Makefile on an FMA-capable x86 host (default) */
+#define SELHIP_FP_STRICT     0     /* = reference built with -ffp-contract=off                              */
+
+/* ---------------------------------------------------------------------------------------------------
+ * 1. Drop-in launchers: same names and parameter lists as src/selection_kernels_wrapper.hpp:11-45
+ *    (CUDA int2 -> selhip_int2_t, Result -> selhip_result_t, void -> int status).
+ *    All pointers are device pointers; out must hold total_pairs records (reference contract,
+ *    selection_cuda.cpp:164); *out_count is zeroed by the launcher (selection_kernels.cu:137,166).
+ *    pairs must be non-NULL when total_pairs > 0 (implicit all-pairs enumeration, which never
+ *    materialises the 8 B/pair list, is what the selhip_ctx_* API below is for).
+ *    m_aux is the number of u64 buckets per sketch, m_hll the number of HLL registers (16384).
+ *    launch_kernel_smh evaluates every listed pair; launch_kernel_CBsmh additionally applies CB
+ *    (the reference kernel of that name does not, selection_kernels.cu:63-117 -- documented defect).
+ *    Asynchronous on the null stream, like the reference; blockSize is accepted and ignored
+ *    (the kernels choose their own wave64 geometry).
+ * --------------------------------------------------------------------------------------------------- */
+int launch_kernel_smh(const uint8_t* main_sketches, const uint64_t* aux_sketches, const double* cards,
+                      const selhip_int2_t* pairs, int total_pairs, double tau,
+                      int m_aux, int m_hll, int n_rows, int n_bands,
+                      selhip_result_t* out, int* out_count, int blockSize);
+int launch_kernel_CBsmh(const uint8_t* main_sketches, const uint64_t* aux_sketches, const double* cards,
+                        const selhip_int2_t* pairs, int total_pairs, double tau,
+                        int m_aux, int m_hll, int n_rows, int n_bands,
+                        selhip_result_t* out, int* out_count, int blockSize);
+
+/* ---------------------------------------------------------------------------------------------------
+ * 2. Context API: owns the derived device buffers (truncated cards, CB bounds, band signatures,
+ *    candidate / result lists) that selection_cuda.cpp:152-182 handles with raw CUDA calls.
+ * --------------------------------------------------------------------------------------------------- */
+typedef struct selhip_ctx selhip_ctx;
+
+int  selhip_device_count(void);
+int  selhip_ctx_create(selhip_ctx** out, int device);
+void selhip_ctx_destroy(selhip_ctx* ctx);
+/* message of the last failure on this context (never NULL); ctx may be NULL for creation errors */
+const char* selhip_last_error(const selhip_ctx* ctx);
+
+/* Run all work of this context on `hip_stream` (a hipStream_t passed as void*; NULL = null stream). */
+int selhip_ctx_set_stream(selhip_ctx* ctx, void* hip_stream);
+/* SELHIP_FP_FMA (default) or SELHIP_FP_STRICT */
+int selhip_ctx_set_fp_mode(selhip_ctx* ctx, int fp_mode);
+
+/* Host -> device upload of sketches already in ascending-cardinality order
+ * (the flatten step of selection_cuda.cpp:131-143 + the H2D copies :167-169).
+ *   h_hll [n][1<<p_hll] u8, h_aux [n][m] u64, h_cards [n] f64 (may be NULL: computed on the device
+ *   from the registers with the Ertl-MLE estimator, == hll_t::report()). */
+int selhip_ctx_upload(selhip_ctx* ctx, const uint8_t* h_hll, const uint64_t* h_aux, const double* h_cards,
+                      int64_t n_genomes, int m, int p_hll);
+/* Same, for sketches that already live in device memory (caller keeps ownership and must keep them
+ * alive while the context uses them).  d_cards may be NULL (computed). */
+int selhip_ctx_attach(selhip_ctx* ctx, const uint8_t* d_hll, const uint64_t* d_aux, const double* d_cards,
+                      int64_t n_genomes, int m, int p_hll);
+
+/* report() of every genome (Ertl-MLE, hll.h:834-837,862) computed on the device: d_cards_out[n]. */
+int selhip_hll_cards(selhip_ctx* ctx, const uint8_t* d_hll, int64_t n_genomes, int p, double* d_cards_out);
+/* copies the context's cardinalities to the host */
+int selhip_ctx_get_cards(selhip_ctx* ctx, double* h_cards_out);
+
+/* One pass of the hot path over query rows [row_begin, row_end) (0, n_genomes = everything;
+ * a sub-range is one rank's shard of the pair space: rows are independent).
+ * tau_f is the FLOAT threshold of the reference (`float threshold`, selection.cpp:81,103).
+ * Results stay on the device until fetched.  Synchronous w.r.t. the context's stream on return. */
+int selhip_ctx_run(selhip_ctx* ctx, int mode, int algo, float tau_f, int n_rows, int n_bands,
+                   int64_t row_begin, int64_t row_end);
+/* Asynchronous variant: enqueues the pass and returns; selhip_ctx_finish() waits and validates. */
+int selhip_ctx_run_async(selhip_ctx* ctx, int mode, int algo, float tau_f, int n_rows, int n_bands,
+                         int64_t row_begin, int64_t row_end);
+int selhip_ctx_finish(selhip_ctx* ctx);
+
+/* statistics of the last finished run:
+ *   stats[0] pairs evaluated by the smh_a predicate (after e_k==0 / CB pruning)
+ *   stats[1] stage-1 survivors (pairs with a fully equal band)
+ *   stats[2] selected pairs (J >= tau)
+ *   stats[3] candidates produced by the signature join (ALGO_SIG; = stats[1] for ALGO_STREAM) */
+int selhip_ctx_stats(const selhip_ctx* ctx, int64_t stats[4]);
+int64_t selhip_ctx_result_count(const selhip_ctx* ctx);
+/* copies min(count, cap) records to the host, sorted by (i,k) = the reference's print order */
+int selhip_ctx_fetch(selhip_ctx* ctx, selhip_pair_t* h_out, int64_t cap);
+/* device-side view of the unsorted result list (for RCCL gathers without a host round trip) */
+int selhip_ctx_result_device(selhip_ctx* ctx, const selhip_pair_t** d_results, int64_t* count);
+
+/* average device time (ms, HIP events on the context's stream) of the named kernel over the launches
+ * since the last reset; names: "stage1", "hist", "select", "prep", "total".  <0 if never launched. */
+double selhip_ctx_kernel_ms(const selhip_ctx* ctx, const char* name);
+int    selhip_ctx_timing(selhip_ctx* ctx, int enable);   /* enable/disable + reset event timing */
+
+/* ---------------------------------------------------------------------------------------------------
+ * 3. Building blocks (device pointers), used by the launchers above and exposed for tests.
+ * --------------------------------------------------------------------------------------------------- */
+/* smh_a on an explicit pair list: d_flags[j] = 1 iff pair j has a fully equal band. */
+int selhip_smh_a_pairs(const uint64_t* d_aux, int m, int n_rows, int n_bands,
+                       const selhip_int2_t* d_pairs, int64_t n_pairs, uint8_t* d_flags, void* hip_stream);
+/* union histogram of an explicit pair list: d_counts[j][64] (u32) = counts of max(reg_x, reg_y). */
+int selhip_hll_union_hist(const uint8_t* d_hll, int p, const selhip_int2_t* d_pairs, int64_t n_pairs,
+                          uint32_t* d_counts, void* hip_stream);
+/* Ertl-MLE of n histograms: d_est[j] = ertl_ml_estimate(d_counts[j], p, 64-p, 1e-2). */
+int selhip_ertl_estimate(const uint32_t* d_counts, int64_t n, int p, int fp_mode, double* d_est, void* hip_stream);
+/* bucket-match counts (the by-product the north_star mentions): d_matches[j] = #{b : aux_x[b]==aux_y[b]} */
+int selhip_smh_match_counts(const uint64_t* d_aux, int m, const selhip_int2_t* d_pairs, int64_t n_pairs,
+                            int32_t* d_matches, void* hip_stream);
+
+/* ---------------------------------------------------------------------------------------------------
+ * 4. Synthetic sketches generated directly in HBM (csrc/synth.hpp; stands in for the FASTA->sketch
+ *    rebuild of experiments/src/time_smh_cuda.cpp:181-211).  Output is in GENERATION order (not sorted).
+ * --------------------------------------------------------------------------------------------------- */
+typedef struct {
+    uint64_t seed;
+    int32_t  n_genomes, m, p_aux, cluster_size, mode;
+    uint32_t n_sh_lo, n_sh_hi;
+} selhip_synth_t;
+int selhip_synth_generate(const selhip_synth_t* sp, int64_t g_begin, int64_t g_end,
+                          uint8_t* d_hll /*[g_end-g_begin][16384]*/, uint64_t* d_aux /*[..][m]*/,
+                          uint8_t* d_aux_hll /*[..][1<<p_aux] or NULL*/, void* hip_stream);
+/* gather rows into rank order: dst[r] = src[perm[r]] for row_bytes-sized rows (device pointers) */
+int selhip_permute_rows(const void* d_src, void* d_dst, const int32_t* d_perm, int64_t n_rows,
+                        int64_t row_bytes, void* hip_stream);
+
+/* ---------------------------------------------------------------------------------------------------
+ * 5. Plain device-memory helpers so that a host program needs no HIP headers (the reference driver
+ *    calls cudaMalloc/cudaMemcpy/cudaFree directly, selection_cuda.cpp:160-182).
+ * --------------------------------------------------------------------------------------------------- */
+int selhip_malloc(void** d_ptr, size_t bytes);
+int selhip_free(void* d_ptr);
+int selhip_memcpy_h2d(void* d_dst, const void* h_src, size_t bytes);
+int selhip_memcpy_d2h(void* h_dst, const void* d_src, size_t bytes);
+int selhip_device_synchronize(void);
+
+const char* selhip_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SELECTION_HIP_H */
