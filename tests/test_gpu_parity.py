@@ -1,0 +1,321 @@
+"""Parity tests proper: the HIP path, called through the C ABI (include/selection_hip.h), against the
+CPU oracle on the same seeded inputs, and against the golden outputs of the reference itself.
+Integer / index work is compared bit-exact; Jaccard values are compared bit-exact too (both sides run
+the same IEEE double sequence; flavour FMA = reference Makefile build, STRICT = -ffp-contract=off)."""
+import ctypes as C
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+
+pytestmark = pytest.mark.gpu
+
+import cuda_selection_criteria_amd as pkg  # noqa: E402
+from cuda_selection_criteria_amd import (ALGO_AUTO, ALGO_STREAM, FP_FMA, FP_STRICT, MODE_CB_SMH, MODE_SMH, Selector)  # noqa: E402
+from cuda_selection_criteria_amd.synth import SynthConfig  # noqa: E402
+
+sys.path.insert(0, str(GOLDEN))
+import make_golden  # noqa: E402
+
+EXP = GOLDEN / "expected"
+
+
+def sorted_set(cfg, oracle, fma=1):
+    """host-generated set in rank order (cards by the oracle, sort by the product's std::sort mirror)"""
+    hll, aux, aux_hll = pkg.synth_host(cfg)
+    oracle.set_fma(fma)
+    cards = oracle.cards(hll)
+    oracle.set_fma(1)
+    perm = pkg.sort_by_card(cards)
+    return hll[perm], aux[perm], cards[perm], perm, (aux_hll[perm] if aux_hll.size else aux_hll)
+
+
+def assert_same_pairs(got, want):
+    assert got.shape[0] == want.shape[0], (got.shape[0], want.shape[0])
+    assert np.array_equal(got["i"], want["i"]) and np.array_equal(got["k"], want["k"])
+    # bit-exact doubles
+    assert np.array_equal(got["jaccard"].view(np.uint64), want["jacc"].view(np.uint64))
+
+
+def test_device_present():
+    assert pkg.hip_lib().selhip_device_count() >= 1
+
+
+@pytest.mark.parametrize("name", list(make_golden.GOLDEN_SYNTH))
+@pytest.mark.parametrize("fp_mode", [FP_FMA, FP_STRICT])
+def test_synthetic_vs_oracle_and_golden(oracle, name, fp_mode):
+    cfg = make_golden.GOLDEN_SYNTH[name]
+    hll, aux, cards, perm, _ = sorted_set(cfg, oracle, fp_mode)
+    names = [f"g{g:06d}" for g in perm]
+    flavour = "fma" if fp_mode == FP_FMA else "nofma"
+    oracle.set_fma(fp_mode)
+    try:
+        with Selector(0, fp_mode) as sel:
+            sel.upload(hll, aux, None)                      # cards computed on the device
+            assert np.array_equal(sel.cards().view(np.uint64), cards.view(np.uint64))
+            for tau in sorted({cfg.tau, 0.5}):
+                r, b = pkg.banding(cfg.m, tau)
+                assert (r, b) == oracle.banding(cfg.m, tau)
+                for mode, use_cb in ((MODE_CB_SMH, True), (MODE_SMH, False)):
+                    got = sel.run(tau, mode, r, b)
+                    want, st = oracle.select(hll, aux, cards, tau, r, b, use_cb=use_cb)
+                    assert_same_pairs(got, want)
+                    s = sel.stats()
+                    assert s["evaluated"] == st["evaluated"] and s["survivors"] == st["survivors"]
+                    if use_cb:
+                        text = pkg.format_lines(names, got)
+                        assert text == (EXP / f"{name}_smh_a_h{tau}.{flavour}.txt").read_text()
+    finally:
+        oracle.set_fma(1)
+
+
+@pytest.mark.parametrize("a,h", [(32, 0.9), (32, 0.01), (128, 0.5), (512, 0.01), (512, 0.9), (2048, 0.9), (2048, 0.01),
+                                 (4096, 0.8), (4096, 0.01), (8192, 0.9), (8192, 0.01)])
+def test_influenza_filelist_text(a, h):
+    """the drop-in flow of selection_cuda.cpp on the reference's own fixtures == reference CPU stdout"""
+    import os
+    cwd = os.getcwd()
+    os.chdir(GOLDEN)
+    try:
+        for fp_mode, flavour in ((FP_FMA, "fma"), (FP_STRICT, "nofma")):
+            got = pkg.select_from_filelist("influenza_filelist.txt", h, a, fp_mode=fp_mode)
+            assert got == (EXP / f"influenza_smh_a_a{a}_h{h}.{flavour}.txt").read_text()
+        if h == 0.9:
+            want = (GOLDEN / "results_reference.txt").read_text().replace("datasets/test_influenzaA/", "influenza/")
+            assert pkg.select_from_filelist("influenza_filelist.txt", h, a) == want
+    finally:
+        os.chdir(cwd)
+
+
+def test_row_shards_union_equals_whole(oracle):
+    cfg = make_golden.GOLDEN_SYNTH["synth_flat_n1000_m256"]
+    hll, aux, cards, _, _ = sorted_set(cfg, oracle)
+    r, b = pkg.banding(cfg.m, cfg.tau)
+    with Selector(0) as sel:
+        sel.upload(hll, aux, cards)
+        whole = sel.run(cfg.tau, MODE_CB_SMH, r, b)
+        parts = []
+        bounds = [0, 137, 138, 500, 999, 1000]
+        for lo, hi in zip(bounds[:-1], bounds[1:]):
+            parts.append(sel.run(cfg.tau, MODE_CB_SMH, r, b, rows=(lo, hi)))
+        cat = np.concatenate(parts)
+        assert np.array_equal(cat, whole)
+
+
+def test_edge_cases(oracle):
+    cfg = SynthConfig("edge", 130, 128, 0.9, 77, n_sh_lo=5000, n_sh_hi=5000)
+    hll, aux, cards, _, _ = sorted_set(cfg, oracle)
+    r, b = pkg.banding(cfg.m, cfg.tau)
+    with Selector(0) as sel:
+        # empty set, single genome, two genomes
+        for n in (0, 1, 2, 3):
+            sel.upload(hll[:n], aux[:n], cards[:n])
+            got = sel.run(cfg.tau, MODE_CB_SMH, r, b)
+            want, _ = oracle.select(hll[:n], aux[:n], cards[:n], cfg.tau, r, b)
+            assert_same_pairs(got, want)
+        # genomes with zero cardinality (all-zero registers): `if (e2 == 0) continue` (selection.cpp:281)
+        h2, a2 = hll.copy(), aux.copy()
+        h2[:5] = 0
+        c2 = oracle.cards(h2)
+        perm = pkg.sort_by_card(c2)
+        h2, a2, c2 = h2[perm], a2[perm], c2[perm]
+        assert (c2[:5] == 0).all()
+        sel.upload(h2, a2, c2)
+        for mode, use_cb in ((MODE_CB_SMH, True), (MODE_SMH, False)):
+            got = sel.run(0.5, mode, *pkg.banding(cfg.m, 0.5))
+            want, st = oracle.select(h2, a2, c2, 0.5, *pkg.banding(cfg.m, 0.5), use_cb=use_cb)
+            assert_same_pairs(got, want)
+            assert sel.stats()["evaluated"] == st["evaluated"]
+        # identical sketches (duplicates): every band equal, J == 1-ish; and tau > 1 selects nothing
+        h3, a3 = hll.copy(), aux.copy()
+        h3[1] = h3[0]; a3[1] = a3[0]
+        c3 = oracle.cards(h3)
+        perm = pkg.sort_by_card(c3)
+        h3, a3, c3 = h3[perm], a3[perm], c3[perm]
+        sel.upload(h3, a3, c3)
+        got = sel.run(0.9, MODE_CB_SMH, r, b)
+        want, _ = oracle.select(h3, a3, c3, 0.9, r, b)
+        assert_same_pairs(got, want)
+        assert len(got) >= 1
+        # all band shapes of m=128, including rows=1 and rows=m
+        for rows in (1, 2, 4, 8, 16, 32, 64, 128):
+            got = sel.run(0.3, MODE_SMH, rows, 128 // rows)
+            want, st = oracle.select(h3, a3, c3, 0.3, rows, 128 // rows, use_cb=False)
+            assert_same_pairs(got, want)
+            assert sel.stats()["survivors"] == st["survivors"], rows
+        # bad banding is an error, not a silent empty result
+        with pytest.raises(pkg.SelhipError):
+            sel.run(0.9, MODE_CB_SMH, 3, 5)
+
+
+def test_big_bands_and_generic_shapes(oracle):
+    """rows >= 128 (a band spans whole 128-bucket chunks) and shapes the fast kernel does not cover"""
+    rng = np.random.default_rng(5)
+    for m, shapes in ((512, [(128, 4), (256, 2), (512, 1), (64, 8)]), (96, [(3, 32), (32, 3), (1, 96)]), (64, [(8, 8), (64, 1)])):
+        cfg = SynthConfig("shape", 96, 128, 0.9, 1234 + m, n_sh_lo=4000, n_sh_hi=4000)
+        hll, _, cards, _, _ = sorted_set(cfg, oracle)
+        n = hll.shape[0]
+        # buckets from a tiny alphabet + planted equal bands so that long bands do match sometimes
+        aux = rng.integers(0, 2, size=(n, m), dtype=np.uint64)
+        for g in range(1, n, 3):
+            aux[g] = aux[g - 1]
+            aux[g, rng.integers(0, m)] ^= np.uint64(1)        # differ in exactly one bucket
+        with Selector(0) as sel:
+            sel.upload(hll, aux, cards)
+            for rows, bands in shapes:
+                got = sel.run(0.0, MODE_SMH, rows, bands)
+                want, st = oracle.select(hll, aux, cards, 0.0, rows, bands, use_cb=False)
+                assert sel.stats()["survivors"] == st["survivors"], (m, rows, bands)
+                assert_same_pairs(got, want)
+
+
+def test_building_blocks(oracle):
+    import torch
+    cfg = make_golden.GOLDEN_SYNTH["synth_flat_n300_m512"]
+    hll, aux, cards, _, aux_hll = sorted_set(cfg, oracle)
+    lib = pkg.hip_lib()
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(3)
+    n = hll.shape[0]
+    pairs = np.stack([rng.integers(0, n, 500), rng.integers(0, n, 500)], axis=1).astype(np.int32)
+    pairs[:50, 1] = pairs[:50, 0] // 10 * 10 + (pairs[:50, 0] + 1) % 10     # same-cluster pairs
+    d_pairs = torch.from_numpy(pairs).to(dev)
+    d_hll = torch.from_numpy(hll).to(dev)
+    d_aux = torch.from_numpy(aux.view(np.int64)).to(dev)
+    # union histograms
+    d_counts = torch.zeros((500, 64), dtype=torch.int32, device=dev)
+    pkg._lib.check(lib.selhip_hll_union_hist(d_hll.data_ptr(), 14, d_pairs.data_ptr(), 500, d_counts.data_ptr(), None))
+    counts = d_counts.cpu().numpy().view(np.uint32)
+    for j in range(500):
+        assert np.array_equal(counts[j], oracle.union_hist(hll[pairs[j, 0]], hll[pairs[j, 1]])), j
+    # estimator, both flavours
+    for fp in (FP_FMA, FP_STRICT):
+        d_est = torch.zeros(500, dtype=torch.float64, device=dev)
+        pkg._lib.check(lib.selhip_ertl_estimate(d_counts.data_ptr(), 500, 14, fp, d_est.data_ptr(), None))
+        est = d_est.cpu().numpy()
+        want = np.array([oracle.estimate(counts[j], 14, fp) for j in range(500)])
+        assert np.array_equal(est.view(np.uint64), want.view(np.uint64))
+    # p = 8 auxiliary sketches through the same kernels
+    d_ah = torch.from_numpy(aux_hll).to(dev)
+    pkg._lib.check(lib.selhip_hll_union_hist(d_ah.data_ptr(), 8, d_pairs.data_ptr(), 500, d_counts.data_ptr(), None))
+    counts8 = d_counts.cpu().numpy().view(np.uint32)
+    d_est = torch.zeros(500, dtype=torch.float64, device=dev)
+    pkg._lib.check(lib.selhip_ertl_estimate(d_counts.data_ptr(), 500, 8, FP_FMA, d_est.data_ptr(), None))
+    est8 = d_est.cpu().numpy()
+    for j in range(500):
+        assert np.array_equal(counts8[j], oracle.union_hist(aux_hll[pairs[j, 0]], aux_hll[pairs[j, 1]]))
+        assert est8[j] == oracle.union_size(aux_hll[pairs[j, 0]], aux_hll[pairs[j, 1]], 8)
+    # smh_a flags and bucket-match counts
+    r, b = pkg.banding(cfg.m, cfg.tau)
+    d_flags = torch.zeros(500, dtype=torch.uint8, device=dev)
+    pkg._lib.check(lib.selhip_smh_a_pairs(d_aux.data_ptr(), cfg.m, r, b, d_pairs.data_ptr(), 500, d_flags.data_ptr(), None))
+    flags = d_flags.cpu().numpy()
+    d_mc = torch.zeros(500, dtype=torch.int32, device=dev)
+    pkg._lib.check(lib.selhip_smh_match_counts(d_aux.data_ptr(), cfg.m, d_pairs.data_ptr(), 500, d_mc.data_ptr(), None))
+    mc = d_mc.cpu().numpy()
+    for j in range(500):
+        assert bool(flags[j]) == oracle.smh_a(aux[pairs[j, 0]], aux[pairs[j, 1]], r, b)
+        assert mc[j] == int((aux[pairs[j, 0]] == aux[pairs[j, 1]]).sum())
+    assert flags.sum() > 0
+
+
+def test_estimator_rare_branches(oracle):
+    """hll.h:642 (all registers saturated -> +inf), hll.h:659 log1p start point (gprev > 1.5*a: registers
+    near saturation), empty sketch, single non-empty register -- forced inputs (never hit by random data)"""
+    import torch
+    lib = pkg.hip_lib()
+    dev = torch.device("cuda", 0)
+    hists = []
+    for p in (14, 8):
+        q = 64 - p
+        m = 1 << p
+        def h(d):
+            c = np.zeros(64, dtype=np.uint32)
+            for k, v in d.items():
+                c[k] = v
+            assert c.sum() == m
+            return (p, c)
+        hists += [h({q + 1: m}), h({0: m}), h({0: m - 1, 1: 1}), h({q + 1: m - 1, q: 1}), h({q + 1: m - 7, q - 1: 7}),
+                  h({q: m}), h({q - 2: m // 2, q + 1: m // 2}), h({40: m}), h({1: m}), h({0: 1, q + 1: m - 1})]
+    for p in (14, 8):
+        sub = np.stack([c for pp, c in hists if pp == p])
+        for fp in (FP_FMA, FP_STRICT):
+            d_c = torch.from_numpy(sub.view(np.int32)).to(dev)
+            d_e = torch.zeros(len(sub), dtype=torch.float64, device=dev)
+            pkg._lib.check(lib.selhip_ertl_estimate(d_c.data_ptr(), len(sub), p, fp, d_e.data_ptr(), None))
+            got = d_e.cpu().numpy()
+            want = np.array([oracle.estimate(c, p, fp) for c in sub])
+            assert np.array_equal(got.view(np.uint64), want.view(np.uint64)), (p, fp, got, want)
+        assert np.isinf(want[0]) and want[1] == 0.0
+
+
+def test_drop_in_launchers(oracle):
+    """launch_kernel_smh / launch_kernel_CBsmh with the reference's parameter list (device pointers)"""
+    import torch
+    cfg = make_golden.GOLDEN_SYNTH["synth_spread_n600_m64"]
+    hll, aux, cards, _, _ = sorted_set(cfg, oracle)
+    n = hll.shape[0]
+    lib = pkg.hip_lib()
+    dev = torch.device("cuda", 0)
+    ii, kk = np.triu_indices(n, 1)
+    pairs = np.stack([ii, kk], axis=1).astype(np.int32)           # selection_cuda.cpp:146-150
+    total = pairs.shape[0]
+    d_pairs = torch.from_numpy(pairs).to(dev)
+    d_hll = torch.from_numpy(hll).to(dev)
+    d_aux = torch.from_numpy(aux.view(np.int64)).to(dev)
+    d_cards = torch.from_numpy(cards).to(dev)
+    d_out = torch.zeros((total, 3), dtype=torch.int32, device=dev)
+    d_cnt = torch.full((1,), -1, dtype=torch.int32, device=dev)
+    tau = np.float32(cfg.tau)
+    r, b = pkg.banding(cfg.m, cfg.tau)
+    for fn, use_cb in ((lib.launch_kernel_smh, False), (lib.launch_kernel_CBsmh, True)):
+        rc = fn(d_hll.data_ptr(), d_aux.data_ptr(), d_cards.data_ptr(), d_pairs.data_ptr(), total, float(tau),
+                cfg.m, 16384, r, b, d_out.data_ptr(), d_cnt.data_ptr(), 256)
+        assert rc == 0, lib.selhip_last_error(None)
+        torch.cuda.synchronize()
+        cnt = int(d_cnt.item())
+        rec = d_out[:cnt].cpu().numpy()
+        got = sorted((int(x), int(y), np.int32(s).view(np.float32)) for x, y, s in rec)
+        want, _ = oracle.select(hll, aux, cards, cfg.tau, r, b, use_cb=use_cb)
+        exp = [(int(w["i"]), int(w["k"]), np.float32(w["jacc"])) for w in want]
+        assert got == exp
+    # error behaviour: status codes instead of the reference's silent void
+    assert lib.launch_kernel_smh(None, d_aux.data_ptr(), d_cards.data_ptr(), d_pairs.data_ptr(), total, 0.9, cfg.m, 16384, r, b,
+                                 d_out.data_ptr(), d_cnt.data_ptr(), 256) < 0
+    assert lib.launch_kernel_smh(d_hll.data_ptr(), d_aux.data_ptr(), d_cards.data_ptr(), d_pairs.data_ptr(), total, 0.9, cfg.m, 16384, 3, 7,
+                                 d_out.data_ptr(), d_cnt.data_ptr(), 256) < 0
+
+
+def test_device_generator_matches_host():
+    cfg = SynthConfig("gen", 64, 256, 0.9, 99, p_aux=8, mode=1, n_sh_lo=2000, n_sh_hi=30000)
+    hll_h, aux_h, ah_h = pkg.synth_host(cfg)
+    hll_d, aux_d, cards_d, _, ah_d = pkg.synth_device(cfg, sort=False)
+    assert np.array_equal(hll_d.cpu().numpy(), hll_h)
+    assert np.array_equal(aux_d.cpu().numpy().view(np.uint64), aux_h)
+    assert np.array_equal(ah_d.cpu().numpy(), ah_h)
+
+
+def test_attach_device_tensors_and_sorted_generation(oracle):
+    cfg = SynthConfig("attach", 500, 256, 0.9, 4242, n_sh_lo=10000, n_sh_hi=10000)
+    hll_t, aux_t, cards_t, perm, _ = pkg.synth_device(cfg)
+    hll, aux = hll_t.cpu().numpy(), aux_t.cpu().numpy().view(np.uint64)
+    cards = cards_t.cpu().numpy()
+    assert np.array_equal(cards.view(np.uint64), oracle.cards(hll).view(np.uint64))
+    assert (np.diff(cards) >= 0).all()
+    r, b = pkg.banding(cfg.m, cfg.tau)
+    with Selector(0) as sel:
+        sel.attach(hll_t, aux_t, cards_t)
+        got = sel.run(cfg.tau, MODE_CB_SMH, r, b)
+    want, _ = oracle.select(hll, aux, cards, cfg.tau, r, b)
+    assert_same_pairs(got, want)
+    assert len(got) > 100
+
+
+def test_unsorted_cards_rejected(oracle):
+    cfg = SynthConfig("unsorted", 50, 128, 0.9, 5, n_sh_lo=3000, n_sh_hi=3000)
+    hll, aux, cards, _, _ = sorted_set(cfg, oracle)
+    with Selector(0) as sel:
+        with pytest.raises(pkg.SelhipError):
+            sel.upload(hll, aux, cards[::-1].copy())
