@@ -1,0 +1,230 @@
+#!/usr/bin/env python3
+"""bench.py -- BASELINE.json's metric: sketch pair-comparisons/sec (N genomes x m buckets).
+
+A "step" = one pass of the hot path (mode "smh_a" of experiments/src/time_smh.cpp:229-257: every pair
+i<k goes through the smh_a band predicate, survivors through the HLL-14 union estimate and the Jaccard
+test) over one synthetic sketch set that is already resident in HBM, ending with the selected-pair
+list of all ranks gathered on every rank (RCCL all_gather over xGMI when --gpus > 1).
+
+Workload at 1 GPU: BASELINE.json configs[2] = 10 000 synthetic genomes, smh_a m=512, tau=0.8 -- the
+configuration the north_star target (>= 1e10 m=512 bucket-pair-comparisons/s, >= 40 % of the HBM
+roofline) is quoted on.  At N GPUs the genome count is scaled by sqrt(N) (per-GPU pair count fixed:
+weak scaling) and the pair space is sharded by query rows, equal pairs per rank; every rank holds a
+full replica of the sketches.
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with the extra objects `roofline`
+(dominant kernel = stage 1, HIP-event timed inside the timed region) and `cpu_baseline` (the oracle,
+an OpenMP port of selection.cpp's loop, on a bounded sample; N=1 only).
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip-level parameters)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="cfg3", help="key of cuda_selection_criteria_amd.synth.SYNTH_CONFIGS")
+    ap.add_argument("--genomes", type=int, default=0, help="override the genome count (0 = config value, scaled by sqrt(gpus))")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
+    ap.add_argument("--mode", choices=["smh_a", "CB+smh_a"], default="smh_a")
+    ap.add_argument("--algo", choices=["auto", "stream", "sig"], default="auto")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the baseline sample")
+    return ap.parse_args()
+
+
+def main():
+    args = parse()
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    import cuda_selection_criteria_amd as pkg
+    from cuda_selection_criteria_amd import _lib
+    from cuda_selection_criteria_amd.selection import PAIR_DTYPE
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+        args.gpus = world
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs an MI355X: the product path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    base = pkg.SYNTH_CONFIGS[args.workload]
+    n_genomes = args.genomes or base.n_genomes
+    if args.scaling == "weak" and world > 1 and not args.genomes:
+        n_genomes = int(round(base.n_genomes * math.sqrt(world) / base.cluster_size)) * base.cluster_size
+    cfg = base.scaled(n_genomes) if n_genomes != base.n_genomes else base
+    mode = pkg.MODE_SMH if args.mode == "smh_a" else pkg.MODE_CB_SMH
+    algo = {"auto": pkg.ALGO_AUTO, "stream": pkg.ALGO_STREAM, "sig": pkg.ALGO_SIG}[args.algo]
+    n_rows, n_bands = pkg.banding(cfg.m, cfg.tau)
+
+    # ---- inputs: generated in HBM, sorted into rank order (identical replica on every rank) --------------
+    hll_t, aux_t, cards_t, _, _ = pkg.synth_device(cfg, device=local_rank)
+    cards = cards_t.cpu().numpy()
+    sel = pkg.Selector(local_rank)
+    sel.attach(hll_t, aux_t, cards_t)
+
+    # ---- shard the pair space by query rows: equal pair counts per rank ------------------------------------
+    bounds = np.zeros(world + 1, dtype=np.int64)
+    hi = None
+    if mode == pkg.MODE_CB_SMH:
+        e = cards.astype(np.uint64)          # truncation like (size_t)card
+        tau64 = float(np.float32(cfg.tau))
+        hi = np.empty(n_genomes, dtype=np.int32)
+        for i in range(n_genomes):           # monotone: binary search per row (host plan, outside the timed region)
+            lo_, hi_ = i, n_genomes - 1
+            while lo_ < hi_:
+                mid = (lo_ + hi_ + 1) // 2
+                ok = e[mid] == 0 or (float(e[i]) / float(e[mid]) >= tau64)
+                if ok:
+                    lo_ = mid
+                else:
+                    hi_ = mid - 1
+            hi[i] = lo_
+    z0 = int(np.argmax(cards >= 1.0)) if (cards >= 1.0).any() else n_genomes
+    rc = pkg.host_lib().selhost_shard_rows(n_genomes, hi.ctypes.data if hi is not None else None, z0, world, bounds.ctypes.data)
+    assert rc == 0
+    row_lo, row_hi = int(bounds[rank]), int(bounds[rank + 1])
+
+    # gather buffers (fixed capacity so that the timed loop allocates nothing)
+    cap_records = max(1 << 16, 8 * n_genomes)
+    send = torch.zeros((cap_records, 2), dtype=torch.int64, device=dev)          # 16 B records
+    counts_t = torch.zeros(world, dtype=torch.int64, device=dev)
+    my_count = torch.zeros(1, dtype=torch.int64, device=dev)
+    recv = torch.zeros((world, cap_records, 2), dtype=torch.int64, device=dev) if world > 1 else None
+
+    def step():
+        sel.run(cfg.tau, mode, n_rows, n_bands, rows=(row_lo, row_hi), algo=algo, fetch=False)
+        cnt = sel.result_count()
+        if cnt > cap_records:
+            raise RuntimeError("gather buffer too small")
+        sel.copy_results_to(send)
+        if world > 1:
+            my_count.fill_(cnt)
+            dist.all_gather_into_tensor(counts_t, my_count)                       # RCCL
+            dist.all_gather_into_tensor(recv.view(-1), send.view(-1))             # RCCL over xGMI
+        return cnt
+
+    def sync_all():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        step()
+    sel.timing(True)
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        n_sel_local = step()
+    sync_all()
+    dt = time.perf_counter() - t0
+    st = sel.stats()
+    stage1_ms = sel.kernel_ms("stage1")
+    others_ms = {k: sel.kernel_ms(k) for k in ("prep", "hist", "select", "total")}
+
+    t_max = torch.tensor([dt], dtype=torch.float64, device=dev)
+    totals = torch.tensor([st["evaluated"], st["survivors"], st["selected"]], dtype=torch.int64, device=dev)
+    s1 = torch.tensor([stage1_ms], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t_max, op=dist.ReduceOp.MAX)
+        dist.all_reduce(totals, op=dist.ReduceOp.SUM)
+        dist.all_reduce(s1, op=dist.ReduceOp.MAX)
+    dt = float(t_max.item())
+    pairs_per_step = int(totals[0].item())
+    value = pairs_per_step * args.steps / dt
+
+    # ---- result check outside the timed region: gathered list == union of shards, sorted unique ------------
+    if world > 1:
+        cts = counts_t.cpu().numpy()
+        assert int(cts.sum()) == int(totals[2].item()), (cts, totals)
+
+    out = None
+    if rank == 0:
+        pairs_per_launch_rank0 = st["evaluated"]
+        alg_bytes = pairs_per_launch_rank0 * 8 * cfg.m           # 8*m bytes per pair-comparison
+        achieved = alg_bytes / (stage1_ms * 1e-3) / 1e9 if stage1_ms > 0 else None
+        traffic = None
+        tfile = ROOT / "profiles" / "stage1_traffic.json"
+        if tfile.exists():
+            try:
+                traffic = json.loads(tfile.read_text()).get(f"{args.workload}:{args.algo}")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "sketch pair-comparisons/sec (N genomes x m buckets)",
+            "value": value, "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": args.scaling,
+            "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+            "config": {"workload": f"{cfg.name}; mode {args.mode}; bands {n_bands} x {n_rows} rows; "
+                                   f"pair space sharded by query rows over {world} GPU(s), selected pairs all_gathered",
+                       "n_genomes": n_genomes, "m": cfg.m, "tau": cfg.tau, "algo": args.algo,
+                       "pairs_per_step": pairs_per_step, "selected_pairs": int(totals[2].item()),
+                       "stage1_survivors": int(totals[1].item())},
+            "bucket_pair_comparisons_per_s": value * cfg.m,
+            "roofline": {"bound": "hbm", "kernel": "smh_stream_kernel (stage 1)", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
+                         "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": stage1_ms,
+                         "note": "algorithmic bytes = 8*m per pair (one candidate sketch per pair, query in LDS); "
+                                 "each streamed candidate is compared against a tile of query sketches held on chip, "
+                                 "so the algorithmic rate may exceed the HBM peak; `traffic` = measured HBM bytes/launch"},
+            "kernel_ms": {"stage1": stage1_ms, **others_ms},
+        }
+
+    # ---- CPU baseline: the oracle (OpenMP port of selection.cpp:270-291 / time_smh.cpp:229-257) on a bounded sample
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        sys.path.insert(0, str(ROOT / "tests"))
+        import oracle_py
+        orc = oracle_py.Oracle()
+        cores = os.cpu_count() or 1
+        use_cb = mode == pkg.MODE_CB_SMH
+
+        def cpu_run(ns):
+            h = hll_t[:ns].cpu().numpy()
+            a = aux_t[:ns].cpu().numpy().view(np.uint64)
+            c = cards[:ns]
+            t = time.perf_counter()
+            pairs, s = orc.select(h, a, c, cfg.tau, n_rows, n_bands, use_cb=use_cb, threads=cores)
+            return time.perf_counter() - t, s["evaluated"], len(pairs)
+
+        ns = min(n_genomes, 2000)
+        t_probe, ev, _ = cpu_run(ns)
+        rate = ev / max(t_probe, 1e-9)
+        ns2 = int(min(n_genomes, max(ns, math.sqrt(2 * rate * args.cpu_seconds))))
+        if ns2 > ns * 1.2:
+            t_probe, ev, nsel = cpu_run(ns2)
+            ns = ns2
+        out["cpu_baseline"] = {"value": ev / t_probe, "unit": "pairs/s", "cores": cores, "kind": "port",
+                               "sample": f"first {ns} genomes (rank order) of the same set: {ev} pairs in {t_probe:.2f} s, "
+                                         f"oracle/liboracle.so orc_select, OpenMP schedule(dynamic) over rows"}
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    sel.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

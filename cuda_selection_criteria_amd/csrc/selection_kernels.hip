@@ -1080,6 +1080,17 @@ int selhip_ctx_result_device(selhip_ctx* c, const selhip_pair_t** d_results, int
     return SELHIP_OK;
 }
 
+int selhip_ctx_copy_results(selhip_ctx* c, selhip_pair_t* d_dst, int64_t cap) {
+    if (!c || cap < 0 || (cap > 0 && !d_dst)) return SELHIP_E_BADARG;
+    if (!c->have_run) return SELHIP_E_STATE;
+    const int64_t cnt = std::min<int64_t>((int64_t)c->last.n_results, cap);
+    if (cnt > 0) {
+        HIPCHK(&c->err, hipSetDevice(c->device));
+        HIPCHK(&c->err, hipMemcpyAsync(d_dst, c->results.p, (size_t)cnt * sizeof(selhip_pair_t), hipMemcpyDeviceToDevice, c->stream));
+    }
+    return SELHIP_OK;
+}
+
 int selhip_ctx_timing(selhip_ctx* c, int enable) {
     if (!c) return SELHIP_E_BADARG;
     (void)hipStreamSynchronize(c->stream);

@@ -180,6 +180,12 @@ class Selector:
         check(self._lib.selhip_ctx_result_device(self._ctx, C.byref(p), C.byref(cnt)), self._ctx)
         return (p.value or 0), cnt.value
 
+    def copy_results_to(self, tensor) -> int:
+        """D2D copy of the unsorted result records into a torch CUDA uint8/any tensor (>= 16 B per record)."""
+        cap = tensor.numel() * tensor.element_size() // PAIR_DTYPE.itemsize
+        check(self._lib.selhip_ctx_copy_results(self._ctx, tensor.data_ptr(), cap), self._ctx)
+        return min(cap, self.result_count())
+
     def stats(self) -> dict:
         st = (C.c_int64 * 4)()
         check(self._lib.selhip_ctx_stats(self._ctx, st), self._ctx)

@@ -137,6 +137,9 @@ int64_t selhip_ctx_result_count(const selhip_ctx* ctx);
 int selhip_ctx_fetch(selhip_ctx* ctx, selhip_pair_t* h_out, int64_t cap);
 /* device-side view of the unsorted result list (for RCCL gathers without a host round trip) */
 int selhip_ctx_result_device(selhip_ctx* ctx, const selhip_pair_t** d_results, int64_t* count);
+/* device-to-device copy of min(count, cap) unsorted records into caller memory (e.g. a torch tensor that
+ * is then handed to an RCCL collective); asynchronous on the context's stream. */
+int selhip_ctx_copy_results(selhip_ctx* ctx, selhip_pair_t* d_dst, int64_t cap);
 
 /* average device time (ms, HIP events on the context's stream) of the named kernel over the launches
  * since the last reset; names: "stage1", "hist", "select", "prep", "total".  <0 if never launched. */
