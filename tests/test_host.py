@@ -1,0 +1,218 @@
+"""Host-side logic (libselhost.so) and the C-ABI surface -- no GPU needed."""
+import ctypes as C
+import math
+import re
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, ROOT
+
+import cuda_selection_criteria_amd as pkg
+from cuda_selection_criteria_amd import _lib
+from cuda_selection_criteria_amd.synth import SynthConfig
+
+EXP = GOLDEN / "expected"
+
+
+def _declared_functions(header):
+    text = (ROOT / "include" / header).read_text()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    names = re.findall(r"\b([A-Za-z_][A-Za-z0-9_]*)\s*\(", text)
+    return sorted({n for n in names if n.startswith(("selhip_", "selhost_", "launch_kernel_"))})
+
+
+def test_abi_exports_every_declared_symbol():
+    """both libraries load without a GPU and export exactly what include/*.h declares"""
+    hip, host = pkg.hip_lib(), pkg.host_lib()
+    dh = _declared_functions("selection_hip.h")
+    assert set(dh) == set(_lib.HIP_SYMBOLS), set(dh) ^ set(_lib.HIP_SYMBOLS)
+    for n in dh:
+        assert getattr(hip, n) is not None
+    ds = _declared_functions("selection_host.h")
+    assert set(ds) == set(_lib.HOST_SYMBOLS), set(ds) ^ set(_lib.HOST_SYMBOLS)
+    for n in ds:
+        assert getattr(host, n) is not None
+    assert b"gfx950" in hip.selhip_version()
+
+
+def test_no_gpu_fails_loudly():
+    """without a device the product path raises; it never computes on the CPU"""
+    if pkg.hip_lib().selhip_device_count() > 0:
+        pytest.skip("a GPU is present")
+    with pytest.raises(pkg.SelhipError):
+        pkg.Selector(0)
+
+
+def test_product_does_not_import_oracle():
+    import subprocess
+    r = subprocess.run(["grep", "-rIl", "-e", "oracle", str(ROOT / "cuda_selection_criteria_amd"), "--include=*.py",
+                        "--include=*.cpp", "--include=*.hip", "--include=*.hpp", "--include=Makefile"], capture_output=True, text=True)
+    assert r.stdout.strip() == "", r.stdout
+
+
+def test_banding_matches_oracle(oracle):
+    for m in (4, 8, 16, 64, 96, 128, 256, 512, 1024, 2048):
+        for tau in (0.01, 0.3, 0.5, 0.8, 0.9, 0.95, 0.99, 0.999, 1.0):
+            assert pkg.banding(m, tau) == oracle.banding(m, tau), (m, tau)
+            assert pkg.banding(m, tau, pkg.BANDING_CUDA) == oracle.banding(m, tau, cuda_variant=True)
+    assert pkg.banding(256, 0.9) == (16, 16) and pkg.banding(512, 0.8) == (8, 64)
+
+
+def _read_hll(host, path, cap=1 << 14):
+    core = np.zeros(cap, dtype=np.uint8)
+    p, hdr, val = C.c_uint32(), (C.c_uint32 * 4)(), C.c_double()
+    rc = host.selhost_read_hll(str(path).encode(), core.ctypes.data, cap, C.byref(p), hdr, C.byref(val))
+    assert rc == 0, host.selhost_last_error()
+    return core[:1 << p.value], p.value, list(hdr), val.value
+
+
+@pytest.mark.parametrize("flavour,fp", [("fma", 1), ("nofma", 0)])
+@pytest.mark.parametrize("suffix", [".hll", ".hll_8"])
+def test_host_estimator_kat(host, flavour, fp, suffix):
+    """csrc/ertl_mle.hpp compiled for the host == the reference's hll_t report()/union_size(), hex-exact"""
+    files = [l.strip() for l in (GOLDEN / "influenza_filelist.txt").read_text().splitlines() if l.strip()]
+    regs = [_read_hll(host, GOLDEN / (f + suffix)) for f in files]
+    assert regs[0][2] == [0, 2, 2, 1] and regs[0][3] == -1.0          # header written by build_sketch
+    for line in (EXP / f"influenza_kat{suffix.replace('.', '_')}.{flavour}.txt").read_text().splitlines():
+        t = line.split()
+        if t[0] == "R":
+            r = regs[int(t[1])]
+            v = host.selhost_hll_report(r[0].ctypes.data, r[1], fp)
+        else:
+            a, b = regs[int(t[1])], regs[int(t[2])]
+            v = host.selhost_hll_union_size(a[0].ctypes.data, b[0].ctypes.data, a[1], fp)
+        assert v == float.fromhex(t[-1]), line
+
+
+def test_estimator_vs_oracle_random_histograms(host, oracle):
+    rng = np.random.default_rng(11)
+    for p in (4, 6, 8, 10, 14):
+        m = 1 << p
+        for trial in range(300):
+            scale = rng.uniform(0.05, 40.0)
+            regs = np.minimum(rng.geometric(0.5, m) + rng.integers(0, int(scale) + 1, m) - 1, 64 - p + 1)
+            if trial % 7 == 0:
+                regs[rng.random(m) < 0.5] = 0
+            if trial % 11 == 0:
+                regs[:] = np.minimum(regs + 64 - p - 4, 64 - p + 1)      # near saturation: log1p start-point branch
+            c = np.bincount(regs, minlength=64).astype(np.uint32)
+            for fp in (0, 1):
+                got = host.selhost_ertl_estimate(c.ctypes.data, p, fp)
+                want = oracle.estimate(c, p, fp)
+                assert got == want or (math.isnan(got) and math.isnan(want)), (p, trial, fp, got, want)
+
+
+def test_log1p_restatement_matches_libm(host):
+    rng = np.random.default_rng(1)
+    xs = np.concatenate([rng.uniform(-0.999, 10, 20000), 10 ** rng.uniform(-320, 300, 20000), -10 ** rng.uniform(-320, -0.001, 5000),
+                         [0.0, -0.0, 1.5, 2.0, 1e-30, 2 ** -29, 2 ** -54, 0.41421356, -0.2928932, float("inf")]])
+    bad = 0
+    for x in xs:
+        a, b = host.selhost_log1p(float(x)), math.log1p(float(x))
+        if a != b:
+            bad += 1
+    assert bad == 0
+
+
+def test_formats_roundtrip_and_errors(tmp_path, host):
+    rng = np.random.default_rng(2)
+    core = rng.integers(0, 40, 1 << 14, dtype=np.uint8)
+    assert host.selhost_write_hll(str(tmp_path / "a.hll").encode(), core.ctypes.data, 14) == 0
+    back, p, hdr, val = _read_hll(host, tmp_path / "a.hll")
+    assert p == 14 and hdr == [0, 2, 2, 1] and val == -1.0 and np.array_equal(back, core)
+    v = rng.integers(0, 2 ** 63, 512, dtype=np.uint64)
+    assert host.selhost_write_smh(str(tmp_path / "a.smh512").encode(), v.ctypes.data, 512) == 0
+    out = np.zeros(512, dtype=np.uint64)
+    assert host.selhost_read_smh(str(tmp_path / "a.smh512").encode(), out.ctypes.data, 512) == 512
+    assert np.array_equal(out, v)
+    # byte-level format: gz( u32 count | u64[count] ) and gz( u32[4] | u32 np | f64 | u8[1<<np] )
+    import gzip
+    import struct
+    raw = gzip.open(tmp_path / "a.smh512", "rb").read()
+    assert len(raw) == 4 + 8 * 512 and struct.unpack_from("<I", raw)[0] == 512
+    raw = gzip.open(tmp_path / "a.hll", "rb").read()
+    assert len(raw) == 16 + 4 + 8 + (1 << 14)
+    # shipped fixture == what the reader expects
+    shipped = gzip.open(GOLDEN / "influenza" / "GCA_037915005.1_ASM3791500v1_genomic.fna.gz.smh64", "rb").read()
+    assert len(shipped) == 4 + 8 * 64
+    # errors: missing file, short buffer
+    assert host.selhost_read_smh(b"/nonexistent/x.smh4", out.ctypes.data, 4) < 0
+    assert b"Could not open" in host.selhost_last_error()
+    small = np.zeros(16, dtype=np.uint8)
+    assert host.selhost_read_hll(str(tmp_path / "a.hll").encode(), small.ctypes.data, 16, None, None, None) < 0
+
+
+def test_dataset_load_sorted_flattened(host, oracle):
+    import os
+    cwd = os.getcwd()
+    os.chdir(GOLDEN)
+    try:
+        ds = pkg.load_dataset("influenza_filelist.txt", 64, p_aux=8)
+    finally:
+        os.chdir(cwd)
+    assert ds.hll.shape == (10, 16384) and ds.aux.shape == (10, 64) and ds.aux_hll.shape == (10, 256)
+    assert (np.diff(ds.cards) >= 0).all()
+    assert np.array_equal(ds.cards.view(np.uint64), oracle.cards(ds.hll).view(np.uint64))
+    # report() KATs in file-list order
+    files = [l.strip() for l in (GOLDEN / "influenza_filelist.txt").read_text().splitlines() if l.strip()]
+    kat = {files[0]: 13261.219083876271, files[1]: 12968.31998261073, files[2]: 12971.461171021954}
+    for name, card in zip(ds.names, ds.cards):
+        if name in kat:
+            assert card == kat[name]
+    with pytest.raises(RuntimeError):
+        pkg.load_dataset("/nonexistent/list.txt", 64)
+
+
+def test_sort_mirror_is_a_sort(host):
+    rng = np.random.default_rng(4)
+    cards = rng.integers(0, 50, 1000).astype(np.float64)          # many ties
+    perm = pkg.sort_by_card(cards)
+    assert sorted(perm.tolist()) == list(range(1000))
+    assert (np.diff(cards[perm]) >= 0).all()
+
+
+def test_format_line(host):
+    buf = C.create_string_buffer(256)
+    w = host.selhost_format_line(b"a.fna.gz", b"b.fna.gz", 0.94610712345, buf, 256)
+    assert buf.raw[:w] == b"a.fna.gz b.fna.gz 0.946107\n"
+    assert host.selhost_format_line(b"a", b"b", 1.0, buf, 3) < 0
+
+
+def test_synth_host_deterministic_and_statistics(oracle):
+    cfg = SynthConfig("t", 40, 256, 0.9, 123, p_aux=8, n_sh_lo=20000, n_sh_hi=20000)
+    a1 = pkg.synth_host(cfg)
+    a2 = pkg.synth_host(cfg, threads=1)
+    for x, y in zip(a1, a2):
+        assert np.array_equal(x, y)
+    part = pkg.synth_host(cfg, (10, 20))
+    assert np.array_equal(part[0], a1[0][10:20]) and np.array_equal(part[1], a1[1][10:20])
+    hll, aux, ah = a1
+    cards = oracle.cards(hll)
+    assert (np.abs(cards / 20000 - 1.05) < 0.08).all()            # n_sh + n_sh*f, f <= 0.1
+    same = (aux[0] == aux[1]).mean()                               # same cluster: J >= 0.83
+    other = (aux[0] == aux[10]).mean()                             # different cluster: unrelated
+    assert same > 0.7 and other < 0.05
+    assert oracle.report(ah[0], 8) > 0
+
+
+def test_shard_rows_equal_pairs():
+    from cuda_selection_criteria_amd import distributed as D
+    n = 10000
+    for world in (1, 2, 3, 4, 8):
+        b = D.shard_rows(n, world)
+        assert b[0] == 0 and b[-1] == n and (np.diff(b) >= 0).all()
+        pc = D.pair_counts(n, b)
+        assert pc.sum() == n * (n - 1) // 2
+        assert pc.max() <= pc.mean() * 1.01 + n
+    # CB-banded pair space
+    cards = np.sort(np.random.default_rng(0).uniform(1e4, 3e5, 3000))
+    hi = D.cb_bounds(cards, 0.9)
+    e = cards.astype(np.uint64).astype(np.float64)
+    for i in (0, 17, 1500, 2999):
+        k = hi[i]
+        assert e[i] / e[k] >= float(np.float32(0.9)) and (k == 2999 or e[i] / e[k + 1] < float(np.float32(0.9)))
+    b = D.shard_rows(3000, 4, hi)
+    pc = D.pair_counts(3000, b, hi)
+    assert pc.sum() == int(np.maximum(hi.astype(np.int64) - np.arange(3000), 0).sum())
+    assert pc.max() <= pc.mean() * 1.05 + 3000
