@@ -1,0 +1,49 @@
+"""The C++ host programs: `selection` (drop-in CLI of src/selection_cuda.cpp / README.md:60-66) and
+`time_smh_hip` (experiments/src/time_smh_cuda.cpp counterpart)."""
+import subprocess
+
+import pytest
+
+from conftest import GOLDEN, ROOT
+
+BIN = ROOT / "cuda_selection_criteria_amd" / "bin"
+EXP = GOLDEN / "expected"
+
+
+def test_usage_without_gpu():
+    out = subprocess.run([str(BIN / "selection"), "-x"], capture_output=True, text=True)
+    assert out.returncode == 0 and out.stdout.startswith("Usage: -l -h -a -b")
+    out = subprocess.run([str(BIN / "time_smh_hip"), "-x"], capture_output=True, text=True)
+    assert out.returncode == 0 and "Usage" in out.stdout
+
+
+def test_missing_list_is_an_error():
+    out = subprocess.run([str(BIN / "selection"), "-l", "/nonexistent/list.txt", "-h", "0.9", "-a", "512"], capture_output=True, text=True)
+    assert out.returncode != 0 and "No valid input file provided" in out.stderr     # selection.cpp:48-52
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("a,h", [(32, "0.9"), (512, "0.01"), (2048, "0.9"), (4096, "0.01"), (8192, "0.5")])
+def test_selection_cli_matches_reference_stdout(a, h):
+    for flag, flavour in (("1", "fma"), ("0", "nofma")):
+        out = subprocess.run([str(BIN / "selection"), "-l", "influenza_filelist.txt", "-h", h, "-a", str(a), "-b", "128", "-F", flag],
+                             cwd=GOLDEN, capture_output=True, text=True)
+        assert out.returncode == 0, out.stderr
+        assert out.stdout == (EXP / f"influenza_smh_a_a{a}_h{h}.{flavour}.txt").read_text()
+    if h == "0.9":
+        want = (GOLDEN / "results_reference.txt").read_text().replace("datasets/test_influenzaA/", "influenza/")
+        assert out.stdout == want
+
+
+@pytest.mark.gpu
+def test_time_smh_hip_records():
+    out = subprocess.run([str(BIN / "time_smh_hip"), "-l", "influenza_filelist.txt", "-h", "0.9", "-m", "256", "-b", "256"],
+                         cwd=GOLDEN, capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+    lines = out.stdout.strip().splitlines()
+    labels = [l.split(";")[1] for l in lines]
+    assert labels == ["build_smh", "smh_a", "CB+smh_a"]
+    assert ";r:16_b:16;" in lines[1] and "pairs:45;" in lines[1] and "selected:7;" in lines[2]
+    out = subprocess.run([str(BIN / "time_smh_hip"), "-N", "2000", "-h", "0.9", "-m", "256"], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+    assert "synthetic_N2000;smh_a;0.9;" in out.stdout and "pairs:1999000;" in out.stdout
