@@ -288,6 +288,121 @@ void smh_generic_kernel(const u64* __restrict__ aux, int n, int m, int n_rows, i
     }
 }
 
+
+// =============================================================================================
+// ALGO_SIG -- stage 1 as a signature join (exact):
+//   a pair passes smh_a iff SOME band of r buckets is entirely equal (criteria_sketch.hpp:66-81).  Equal bands
+//   have equal 32-bit signatures (a hash of the band's r u64 values), so "some band signature equal" is a
+//   necessary condition; pairs that meet it are CANDIDATES and are verified with the literal predicate on the
+//   full sketches (verify_kernel).  A hash collision only adds a candidate that the verification rejects
+//   (expected n_bands * 2^-32 per pair), it can never drop a pair: the survivor set is identical to the
+//   stream kernel's.  The all-pairs part then costs n_bands 32-bit compares per pair instead of m 64-bit ones.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ u64 mix64(u64 x) {
+    x ^= x >> 30; x *= 0xBF58476D1CE4E5B9ull;
+    x ^= x >> 27; x *= 0x94D049BB133111EBull;
+    x ^= x >> 31;
+    return x;
+}
+
+// sig_build_kernel: one thread per bucket, coalesced 8-B loads; the r lanes of a band add their position-salted
+// mixes with xor-shuffles (r <= 64) -- or one thread walks the band (r > 64).  Writes both layouts:
+//   sigQ[g][NB] (query-major, read with scalar loads) and sigT[b][n_pad] (band-major, lane = candidate).
+__global__ __launch_bounds__(kBlock)
+void sig_build_kernel(const u64* __restrict__ aux, int n, int m, int r, int nb, int n_pad,
+                      uint32_t* __restrict__ sigQ, uint32_t* __restrict__ sigT) {
+    if (r <= kWave) {
+        const long long t = (long long)blockIdx.x * kBlock + threadIdx.x;      // global bucket index
+        const long long total = (long long)n * m;
+        u64 h = 0;
+        int j = 0;
+        if (t < total) {
+            j = (int)(t % r);                                                  // position inside the band
+            h = mix64(aux[t] + 0x9E3779B97F4A7C15ull * (u64)(j + 1));
+        }
+        for (int s = 1; s < r; s <<= 1) {                                      // r is a power of two here
+            h += __shfl_xor(h, s, kWave);
+        }
+        if (t < total && j == 0) {
+            const int g = (int)(t / m);
+            const int b = (int)((t % m) / r);
+            const uint32_t sig = (uint32_t)(h ^ (h >> 32));
+            sigQ[(long long)g * nb + b] = sig;
+            sigT[(long long)b * n_pad + g] = sig;
+        }
+    } else {
+        const long long t = (long long)blockIdx.x * kBlock + threadIdx.x;      // (genome, band)
+        if (t >= (long long)n * nb) return;
+        const int g = (int)(t / nb), b = (int)(t % nb);
+        const u64* v = aux + (long long)g * m + (long long)b * r;
+        u64 h = 0;
+        for (int j = 0; j < r; ++j) h += mix64(v[j] + 0x9E3779B97F4A7C15ull * (u64)(j + 1));
+        const uint32_t sig = (uint32_t)(h ^ (h >> 32));
+        sigQ[(long long)g * nb + b] = sig;
+        sigT[(long long)b * n_pad + g] = sig;
+    }
+}
+
+// sig_join_kernel<NB>: lane = candidate k (its NB signatures live in VGPRs), the query's NB signatures are
+// wave-uniform (scalar loads), one v_cmp_eq_u32 per band per 64 pairs, masks OR-ed on the scalar unit.
+//   block = 4 waves = 4 consecutive groups of 64 candidates, one tile of QT query rows.
+constexpr int kJoinQT = 256;
+template <int NB>
+__global__ __launch_bounds__(kBlock)
+void sig_join_kernel(const uint32_t* __restrict__ sigQ, const uint32_t* __restrict__ sigT, int n, int n_pad,
+                     const int* __restrict__ hi, const PassCounters* __restrict__ pc_in,
+                     int row_begin, int row_end, int n_tiles, int group_base,
+                     selhip_int2_t* __restrict__ cand, u64 cand_cap, PassCounters* __restrict__ pc) {
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
+    const int tile = blockIdx.x % n_tiles;
+    const int grp = group_base + (blockIdx.x / n_tiles) * kWavesPerBlock + wave;
+    const int k_base = grp * kWave;
+    if (k_base >= n) return;
+    const int z0 = pc_in->z0;
+    int i_lo = row_begin + tile * kJoinQT;
+    int i_hi = min(min(i_lo + kJoinQT, row_end), k_base + kWave - 1);          // need i < k for some lane
+    if (i_lo >= i_hi || k_base + kWave - 1 < z0) return;
+    // rows whose CB cut-off does not reach this group can be skipped: hi is non-decreasing, test the last row
+    if (hi[i_hi - 1] < k_base) return;
+
+    const int k = k_base + lane;
+    uint32_t c[NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) c[b] = sigT[(long long)b * n_pad + k];         // k < n_pad always
+
+    for (int i = i_lo; i < i_hi; ++i) {
+        const uint32_t* __restrict__ q = sigQ + (long long)i * NB;               // wave-uniform address
+        u64 mask = 0;
+#pragma unroll
+        for (int b = 0; b < NB; ++b) mask |= __ballot(c[b] == q[b]);
+        if (mask) {
+            const int lo = max(i + 1, z0);
+            const int hk = min(hi[i], n - 1);
+            if (((mask >> lane) & 1ull) && k >= lo && k <= hk) {
+                u64 idx = atomicAdd(&pc->n_candidates, 1ull);
+                if (idx < cand_cap) { cand[idx].x = i; cand[idx].y = k; }
+            }
+        }
+    }
+}
+
+// verify_kernel: the literal smh_a on every candidate (one lane per candidate), survivors compacted.
+__global__ __launch_bounds__(kBlock)
+void verify_kernel(const u64* __restrict__ aux, int m, int n_rows, int n_bands,
+                   const selhip_int2_t* __restrict__ cand, const u64* __restrict__ n_cand_dev, u64 cand_cap,
+                   selhip_int2_t* __restrict__ surv, u64 surv_cap, PassCounters* __restrict__ pc) {
+    u64 n_cand = *n_cand_dev;
+    if (n_cand > cand_cap) n_cand = cand_cap;
+    for (u64 j = (u64)blockIdx.x * kBlock + threadIdx.x; j < n_cand; j += (u64)gridDim.x * kBlock) {
+        const selhip_int2_t pr = cand[j];
+        if (smh_a_lane(aux + (long long)pr.x * m, aux + (long long)pr.y * m, n_rows, n_bands)) {
+            u64 idx = atomicAdd(&pc->n_survivors, 1ull);
+            if (idx < surv_cap) surv[idx] = pr;
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // hll_union_hist_kernel: one wave per pair.  LDS holds a lane-private 64-bin histogram per wave
 // ([bin][lane], conflict-free ds_add_u32), reduced with a rotated column walk.
@@ -625,6 +740,8 @@ struct selhip_ctx {
     DevBuf<uint32_t> counts;
     DevBuf<selhip_pair_t> results;
     DevBuf<selhip_int2_t> self_pairs;
+    DevBuf<selhip_int2_t> cand;         // ALGO_SIG: signature-join candidates
+    DevBuf<uint32_t> sigQ, sigT;        // ALGO_SIG: band signatures, query-major / band-major
     PassCounters* h_pc = nullptr;       // pinned host mirror
 
     // last run parameters (for overflow re-runs)
@@ -748,6 +865,53 @@ hipError_t launch_stage1(selhip_ctx* c, int n_rows, int n_bands, int rb, int re)
     return hipGetLastError();
 }
 
+
+bool sig_supported(int m, int n_rows, int n_bands) {
+    (void)m;
+    return is_pow2(n_rows) && (n_bands == 8 || n_bands == 16 || n_bands == 32 || n_bands == 64 || n_bands == 128);
+}
+
+template <int NB>
+hipError_t launch_join(selhip_ctx* c, int n_pad, int rb, int re) {
+    const int n = (int)c->n;
+    const int n_tiles = (re - rb + kJoinQT - 1) / kJoinQT;
+    const int group_base = ((rb + 1) / kWave / kWavesPerBlock) * kWavesPerBlock;      // candidates k > row_begin
+    const int n_groups = (n + kWave - 1) / kWave - group_base;
+    const int n_gblocks = (n_groups + kWavesPerBlock - 1) / kWavesPerBlock;
+    if (n_tiles <= 0 || n_gblocks <= 0) return hipSuccess;
+    const long long blocks = (long long)n_tiles * n_gblocks;
+    if (blocks > 0x7FFFFFFFll) return hipErrorInvalidValue;
+    hipLaunchKernelGGL((sig_join_kernel<NB>), dim3((unsigned)blocks), dim3(kBlock), 0, c->stream,
+                       c->sigQ.p, c->sigT.p, n, n_pad, c->hi.p, c->pc.p, rb, re, n_tiles, group_base,
+                       c->cand.p, (u64)c->cand.cap, c->pc.p);
+    return hipGetLastError();
+}
+
+hipError_t launch_stage1_sig(selhip_ctx* c, int n_rows, int n_bands, int rb, int re) {
+    const int n = (int)c->n;
+    const int n_pad = ((n + kWave - 1) / kWave) * kWave;
+    {
+        const long long threads = n_rows <= kWave ? (long long)n * c->m : (long long)n * n_bands;
+        hipLaunchKernelGGL(sig_build_kernel, dim3((unsigned)((threads + kBlock - 1) / kBlock)), dim3(kBlock), 0, c->stream,
+                           c->d_aux, n, c->m, n_rows, n_bands, n_pad, c->sigQ.p, c->sigT.p);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
+    }
+    hipError_t e = hipSuccess;
+    switch (n_bands) {
+        case 8: e = launch_join<8>(c, n_pad, rb, re); break;
+        case 16: e = launch_join<16>(c, n_pad, rb, re); break;
+        case 32: e = launch_join<32>(c, n_pad, rb, re); break;
+        case 64: e = launch_join<64>(c, n_pad, rb, re); break;
+        case 128: e = launch_join<128>(c, n_pad, rb, re); break;
+        default: return hipErrorInvalidValue;
+    }
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(verify_kernel, dim3(1024), dim3(kBlock), 0, c->stream, c->d_aux, c->m, n_rows, n_bands,
+                       c->cand.p, &c->pc.p->n_candidates, (u64)c->cand.cap, c->surv.p, (u64)c->surv.cap, c->pc.p);
+    return hipGetLastError();
+}
+
 template <int MODE>
 hipError_t launch_select(bool fma, hipStream_t st, unsigned grid, const uint32_t* counts, const u64* n_dev, u64 n_host,
                          u64 cap, int p, double* est, const selhip_int2_t* pairs, const u64* ecard, double tau,
@@ -802,7 +966,13 @@ int enqueue_pass(selhip_ctx* c) {
     }
     {
         TimerScope t(c, T_STAGE1);
-        HIPCHK(&c->err, launch_stage1(c, c->n_rows, c->n_bands, rb, re));
+        const bool use_sig = (c->algo == SELHIP_ALGO_SIG || c->algo == SELHIP_ALGO_AUTO) && sig_supported(c->m, c->n_rows, c->n_bands);
+        if (c->algo == SELHIP_ALGO_SIG && !use_sig) {
+            set_err(&c->err, "ALGO_SIG needs power-of-two rows and 8..128 bands (got %d x %d)", c->n_rows, c->n_bands);
+            return SELHIP_E_BADARG;
+        }
+        if (use_sig) HIPCHK(&c->err, launch_stage1_sig(c, c->n_rows, c->n_bands, rb, re));
+        else         HIPCHK(&c->err, launch_stage1(c, c->n_rows, c->n_bands, rb, re));
     }
     {
         TimerScope t(c, T_HIST);
@@ -825,6 +995,15 @@ int ensure_scratch(selhip_ctx* c, size_t surv_cap, size_t res_cap) {
     HIPCHK(&c->err, c->hi.ensure((size_t)c->n));
     HIPCHK(&c->err, c->pc.ensure(1));
     HIPCHK(&c->err, c->surv.ensure(surv_cap));
+    HIPCHK(&c->err, c->cand.ensure(surv_cap));
+    {
+        const size_t n_pad = (((size_t)c->n + kWave - 1) / kWave) * kWave;
+        const size_t nb = (size_t)std::max(c->n_bands, 1);
+        if (nb <= 128) {
+            HIPCHK(&c->err, c->sigQ.ensure((size_t)c->n * nb));
+            HIPCHK(&c->err, c->sigT.ensure(n_pad * nb));
+        }
+    }
     HIPCHK(&c->err, c->counts.ensure(std::max(c->surv.cap, (size_t)c->n) * 64));
     HIPCHK(&c->err, c->results.ensure(res_cap));
     if (!c->h_pc) HIPCHK(&c->err, hipHostMalloc((void**)&c->h_pc, sizeof(PassCounters), hipHostMallocDefault));
@@ -880,6 +1059,7 @@ void selhip_ctx_destroy(selhip_ctx* c) {
     c->own_hll.release(); c->own_aux.release(); c->own_cards.release();
     c->ecard.release(); c->hi.release(); c->pc.release(); c->surv.release();
     c->counts.release(); c->results.release(); c->self_pairs.release();
+    c->cand.release(); c->sigQ.release(); c->sigT.release();
     if (c->h_pc) (void)hipHostFree(c->h_pc);
     delete c;
 }
@@ -1016,6 +1196,7 @@ int selhip_ctx_finish(selhip_ctx* c) {
         bool grow = false;
         size_t surv_cap = c->surv.cap, res_cap = c->results.cap;
         if (pc.n_survivors > c->surv.cap) { surv_cap = (size_t)(pc.n_survivors + pc.n_survivors / 8 + 1024); grow = true; }
+        if (pc.n_candidates > c->cand.cap) { surv_cap = std::max(surv_cap, (size_t)(pc.n_candidates + pc.n_candidates / 8 + 1024)); grow = true; }
         if (pc.n_results > c->results.cap) { res_cap = (size_t)(pc.n_results + pc.n_results / 8 + 1024); grow = true; }
         if (!grow) {
             c->last = pc; c->pending = false; c->have_run = true;

@@ -13,7 +13,7 @@ from conftest import GOLDEN
 pytestmark = pytest.mark.gpu
 
 import cuda_selection_criteria_amd as pkg  # noqa: E402
-from cuda_selection_criteria_amd import (ALGO_AUTO, ALGO_STREAM, FP_FMA, FP_STRICT, MODE_CB_SMH, MODE_SMH, Selector)  # noqa: E402
+from cuda_selection_criteria_amd import (ALGO_AUTO, ALGO_SIG, ALGO_STREAM, FP_FMA, FP_STRICT, MODE_CB_SMH, MODE_SMH, Selector)  # noqa: E402
 from cuda_selection_criteria_amd.synth import SynthConfig  # noqa: E402
 
 sys.path.insert(0, str(GOLDEN))
@@ -59,14 +59,20 @@ def test_synthetic_vs_oracle_and_golden(oracle, name, fp_mode):
                 r, b = pkg.banding(cfg.m, tau)
                 assert (r, b) == oracle.banding(cfg.m, tau)
                 for mode, use_cb in ((MODE_CB_SMH, True), (MODE_SMH, False)):
-                    got = sel.run(tau, mode, r, b)
                     want, st = oracle.select(hll, aux, cards, tau, r, b, use_cb=use_cb)
-                    assert_same_pairs(got, want)
-                    s = sel.stats()
-                    assert s["evaluated"] == st["evaluated"] and s["survivors"] == st["survivors"]
-                    if use_cb:
-                        text = pkg.format_lines(names, got)
-                        assert text == (EXP / f"{name}_smh_a_h{tau}.{flavour}.txt").read_text()
+                    for algo in (ALGO_STREAM, ALGO_SIG, ALGO_AUTO):
+                        if algo == ALGO_SIG and b not in (8, 16, 32, 64, 128):
+                            with pytest.raises(pkg.SelhipError):
+                                sel.run(tau, mode, r, b, algo=algo)
+                            continue
+                        got = sel.run(tau, mode, r, b, algo=algo)
+                        assert_same_pairs(got, want)
+                        s = sel.stats()
+                        assert s["evaluated"] == st["evaluated"] and s["survivors"] == st["survivors"], (algo, s, st)
+                        assert s["candidates"] >= s["survivors"]
+                        if use_cb:
+                            text = pkg.format_lines(names, got)
+                            assert text == (EXP / f"{name}_smh_a_h{tau}.{flavour}.txt").read_text()
     finally:
         oracle.set_fma(1)
 
@@ -95,13 +101,15 @@ def test_row_shards_union_equals_whole(oracle):
     r, b = pkg.banding(cfg.m, cfg.tau)
     with Selector(0) as sel:
         sel.upload(hll, aux, cards)
-        whole = sel.run(cfg.tau, MODE_CB_SMH, r, b)
-        parts = []
-        bounds = [0, 137, 138, 500, 999, 1000]
-        for lo, hi in zip(bounds[:-1], bounds[1:]):
-            parts.append(sel.run(cfg.tau, MODE_CB_SMH, r, b, rows=(lo, hi)))
-        cat = np.concatenate(parts)
-        assert np.array_equal(cat, whole)
+        for algo in (ALGO_STREAM, ALGO_SIG):
+            whole = sel.run(cfg.tau, MODE_CB_SMH, r, b, algo=algo)
+            parts = []
+            bounds = [0, 137, 138, 500, 999, 1000]
+            for lo, hi in zip(bounds[:-1], bounds[1:]):
+                parts.append(sel.run(cfg.tau, MODE_CB_SMH, r, b, rows=(lo, hi), algo=algo))
+            cat = np.concatenate(parts)
+            assert np.array_equal(cat, whole)
+            assert len(whole) > 1000
 
 
 def test_edge_cases(oracle):
@@ -141,10 +149,11 @@ def test_edge_cases(oracle):
         assert len(got) >= 1
         # all band shapes of m=128, including rows=1 and rows=m
         for rows in (1, 2, 4, 8, 16, 32, 64, 128):
-            got = sel.run(0.3, MODE_SMH, rows, 128 // rows)
             want, st = oracle.select(h3, a3, c3, 0.3, rows, 128 // rows, use_cb=False)
-            assert_same_pairs(got, want)
-            assert sel.stats()["survivors"] == st["survivors"], rows
+            for algo in (ALGO_STREAM, ALGO_AUTO):
+                got = sel.run(0.3, MODE_SMH, rows, 128 // rows, algo=algo)
+                assert_same_pairs(got, want)
+                assert sel.stats()["survivors"] == st["survivors"], rows
         # bad banding is an error, not a silent empty result
         with pytest.raises(pkg.SelhipError):
             sel.run(0.9, MODE_CB_SMH, 3, 5)
@@ -165,10 +174,11 @@ def test_big_bands_and_generic_shapes(oracle):
         with Selector(0) as sel:
             sel.upload(hll, aux, cards)
             for rows, bands in shapes:
-                got = sel.run(0.0, MODE_SMH, rows, bands)
                 want, st = oracle.select(hll, aux, cards, 0.0, rows, bands, use_cb=False)
-                assert sel.stats()["survivors"] == st["survivors"], (m, rows, bands)
-                assert_same_pairs(got, want)
+                for algo in (ALGO_STREAM, ALGO_AUTO):
+                    got = sel.run(0.0, MODE_SMH, rows, bands, algo=algo)
+                    assert sel.stats()["survivors"] == st["survivors"], (m, rows, bands, algo)
+                    assert_same_pairs(got, want)
 
 
 def test_building_blocks(oracle):
