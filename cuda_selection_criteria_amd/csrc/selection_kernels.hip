@@ -25,6 +25,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -56,6 +57,55 @@ struct PassCounters {
     int z0;              // first rank with e != 0
     int unsorted;        // set if cards are not ascending
     int pad[2];
+};
+
+
+// ---------------------------------------------------------------------------------------------
+// WaveAppender: per-wave staging of output records in LDS, flushed with ONE global atomic per >= 64 records.
+// A returning atomic on a single address sustains only ~90 operations/us chip-wide (MI355X_MICROARCH.md,
+// row "dequeue"), so appending survivors one atomicAdd at a time caps a pass at ~90 survivors/us
+// (45 000 survivors = 0.5 ms -- measured: it was THE cost of the first signature-join kernels).
+// ---------------------------------------------------------------------------------------------
+constexpr int kAppendCap = 2 * kWave;          // count < 64 before a push, a push adds <= 64
+
+struct WaveAppender {
+    selhip_int2_t* buf;        // this wave's LDS staging area [kAppendCap]
+    int count;                 // wave-uniform
+    selhip_int2_t* out;
+    u64 out_cap;
+    u64* out_count;
+
+    __device__ __forceinline__ void init(selhip_int2_t* lds_block, int wave, selhip_int2_t* o, u64 cap, u64* cnt) {
+        buf = lds_block + wave * kAppendCap; count = 0; out = o; out_cap = cap; out_count = cnt;
+    }
+    __device__ __forceinline__ void flush(int lane) {
+        if (count == 0) return;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        u64 base = 0;
+        if (lane == 0) base = atomicAdd(out_count, (u64)count);
+        base = ((u64)__builtin_amdgcn_readfirstlane((int)(base >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)base);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        for (int t = lane; t < count; t += kWave)
+            if (base + (u64)t < out_cap) out[base + (u64)t] = buf[t];
+        count = 0;
+    }
+    // lanes with pred push (x,y); the call must be wave-uniformly reached
+    __device__ __forceinline__ void push(bool pred, int x, int y, int lane) {
+        const u64 m = __ballot(pred);
+        if (m == 0) return;
+        if (pred) {
+            const int off = count + (int)__popcll(m & ((1ull << lane) - 1ull));
+            buf[off].x = x; buf[off].y = y;
+        }
+        count += (int)__popcll(m);
+        if (count >= kWave) flush(lane);
+    }
+    // wave-uniform single record
+    __device__ __forceinline__ void push_uniform(int x, int y, int lane) {
+        if (lane == 0) { buf[count].x = x; buf[count].y = y; }
+        count += 1;
+        if (count >= kWave) flush(lane);
+    }
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -154,7 +204,7 @@ __device__ __forceinline__ u64 band_fold(u64 m0, u64 m1) {
 // dispatch) work on the same candidate chunk, so the chunk is served by that XCD's L2.
 // ---------------------------------------------------------------------------------------------
 template <int NCH, int LOG2R>
-__global__ __launch_bounds__(kBlock, 2)
+__global__ __launch_bounds__(kBlock, (NCH <= 4 ? 3 : 2))      // 3 waves/SIMD = at most 168 VGPRs (measured: 2 waves cost 17 %)
 void smh_stream_kernel(const u64x2* __restrict__ aux, int n, int r_rt,
                        const int* __restrict__ hi, const PassCounters* __restrict__ pc_in,
                        int row_begin, int row_end, int n_tiles, int chunk_base,
@@ -162,6 +212,7 @@ void smh_stream_kernel(const u64x2* __restrict__ aux, int n, int r_rt,
     constexpr int Q = kQueryVgprBudget / NCH;
     constexpr int ROWV = NCH * kWave;                 // u64x2 per sketch row
     __shared__ u64x2 qs[Q * ROWV];
+    __shared__ selhip_int2_t app_lds[kWavesPerBlock * kAppendCap];
 
     const int tile = blockIdx.x % n_tiles;
     const int chunk = blockIdx.x / n_tiles;
@@ -196,6 +247,8 @@ void smh_stream_kernel(const u64x2* __restrict__ aux, int n, int r_rt,
     const int k_end = min(min(k0 + kChunk, n), kmax + 1);
     int k = max(k0, kmin) + wave;
     if (k >= k_end) return;
+    WaveAppender app;
+    app.init(app_lds, wave, surv, surv_cap, &pc->n_survivors);
     // software pipeline: the next candidate's loads are in flight while the current one is compared
     u64x2 cand[NCH], nxt[NCH];
     {
@@ -242,15 +295,11 @@ void smh_stream_kernel(const u64x2* __restrict__ aux, int n, int r_rt,
             }
             if (pass) {
                 const int i = i0 + a;
-                if (i < row_end && k > i && k >= z0 && k <= hi[i]) {
-                    if (lane == 0) {
-                        u64 idx = atomicAdd(&pc->n_survivors, 1ull);
-                        if (idx < surv_cap) { surv[idx].x = i; surv[idx].y = k; }
-                    }
-                }
+                if (i < row_end && k > i && k >= z0 && k <= hi[i]) app.push_uniform(i, k, lane);
             }
         }
     }
+    app.flush(lane);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -274,18 +323,22 @@ void smh_generic_kernel(const u64* __restrict__ aux, int n, int m, int n_rows, i
                         const int* __restrict__ hi, const PassCounters* __restrict__ pc_in,
                         int row_begin, int row_end, int n_rows_grid,
                         selhip_int2_t* __restrict__ surv, u64 surv_cap, PassCounters* __restrict__ pc) {
+    __shared__ selhip_int2_t app_lds[kWavesPerBlock * kAppendCap];
     const int i = row_begin + (int)(blockIdx.x % n_rows_grid);
     const int chunk = blockIdx.x / n_rows_grid;
     if (i >= row_end) return;
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
     const int z0 = pc_in->z0;
     const int kmin = max(i + 1, z0);
     const int kmax = hi[i];
     const int k = kmin + chunk * kBlock + (int)threadIdx.x;
-    if (k > kmax || k >= n) return;
-    if (smh_a_lane(aux + (long long)i * m, aux + (long long)k * m, n_rows, n_bands)) {
-        u64 idx = atomicAdd(&pc->n_survivors, 1ull);
-        if (idx < surv_cap) { surv[idx].x = i; surv[idx].y = k; }
-    }
+    const bool in_range = k <= kmax && k < n;
+    const bool ok = in_range && smh_a_lane(aux + (long long)i * m, aux + (long long)k * m, n_rows, n_bands);
+    WaveAppender app;
+    app.init(app_lds, wave, surv, surv_cap, &pc->n_survivors);
+    app.push(ok, i, k, lane);
+    app.flush(lane);
 }
 
 
@@ -343,15 +396,47 @@ void sig_build_kernel(const u64* __restrict__ aux, int n, int m, int r, int nb, 
     }
 }
 
-// sig_join_kernel<NB>: lane = candidate k (its NB signatures live in VGPRs), the query's NB signatures are
-// wave-uniform (scalar loads), one v_cmp_eq_u32 per band per 64 pairs, masks OR-ed on the scalar unit.
-//   block = 4 waves = 4 consecutive groups of 64 candidates, one tile of QT query rows.
-constexpr int kJoinQT = 256;
+// sig_join_kernel<NB>: all-pairs "some band signature equal", entirely on the vector unit.
+//   lane = candidate k: its NB signatures live in VGPRs c[0..NB)            (loaded once per wave)
+//   queries come 16 at a time: lane l holds the signatures of query i16 + (l & 15) in qv[0..NB) (the four
+//   16-lane rows hold the same 16 queries); query j of the batch is broadcast to every lane by the DPP
+//   modifier row_newbcast:j ON the xor itself (v_xor_b32_dpp), so a band compare costs
+//       t = c[b] ^ bcast_j(qv[b]);  acc = min(acc, t)          (v_xor_b32_dpp + v_min_u32 / v_min3_u32)
+//   with no LDS, scalar-cache or SGPR traffic in the inner loop; acc == 0 iff some band matched.
+// Three earlier forms measured 0.5-0.65 ms on cfg3 and are recorded in DESIGN.md section 4: v_cmp_eq_u32 -> SGPR
+// mask -> s_or_b64 per band; query signatures streamed through scalar loads (the scalar-cache miss path
+// sustains ~0.5 B/clk/CU); query tile in LDS read back with broadcast ds_read_b128 (latency-bound at the
+// occupancy its registers allow).
+template <int J>
+__device__ __forceinline__ uint32_t dpp_row_bcast(uint32_t x) {
+    // DPP_ROW_NEWBCAST (gfx90a+): every lane reads lane J of its own 16-lane row
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x150 + J, 0xF, 0xF, true);
+}
+
+template <int NB, int J>
+__device__ __forceinline__ void join_one_query(const uint32_t (&c)[NB], const uint32_t (&qv)[NB], int i, int i_hi,
+                                               int k, int lane, int z0, int n, const int* __restrict__ hi,
+                                               WaveAppender& app) {
+    // two independent chains of v_min3_u32(acc, x, y): 1.5 VALU per band
+    uint32_t acc0 = 0xFFFFFFFFu, acc1 = 0xFFFFFFFFu;
+#pragma unroll
+    for (int b = 0; b < NB; b += 4) {
+        acc0 = min(min(acc0, c[b] ^ dpp_row_bcast<J>(qv[b])), c[b + 1] ^ dpp_row_bcast<J>(qv[b + 1]));
+        acc1 = min(min(acc1, c[b + 2] ^ dpp_row_bcast<J>(qv[b + 2])), c[b + 3] ^ dpp_row_bcast<J>(qv[b + 3]));
+    }
+    const u64 mm = __ballot(min(acc0, acc1) == 0u);
+    if (mm && i < i_hi) {
+        const int lo = max(i + 1, z0);
+        const int hk = min(hi[i], n - 1);
+        app.push(((mm >> lane) & 1ull) && k >= lo && k <= hk, i, k, lane);
+    }
+}
+
 template <int NB>
 __global__ __launch_bounds__(kBlock)
-void sig_join_kernel(const uint32_t* __restrict__ sigQ, const uint32_t* __restrict__ sigT, int n, int n_pad,
+void sig_join_kernel(const uint32_t* __restrict__ sigT, int n, int n_pad,
                      const int* __restrict__ hi, const PassCounters* __restrict__ pc_in,
-                     int row_begin, int row_end, int n_tiles, int group_base,
+                     int row_begin, int row_end, int n_tiles, int group_base, int qt,
                      selhip_int2_t* __restrict__ cand, u64 cand_cap, PassCounters* __restrict__ pc) {
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
@@ -360,31 +445,31 @@ void sig_join_kernel(const uint32_t* __restrict__ sigQ, const uint32_t* __restri
     const int k_base = grp * kWave;
     if (k_base >= n) return;
     const int z0 = pc_in->z0;
-    int i_lo = row_begin + tile * kJoinQT;
-    int i_hi = min(min(i_lo + kJoinQT, row_end), k_base + kWave - 1);          // need i < k for some lane
-    if (i_lo >= i_hi || k_base + kWave - 1 < z0) return;
-    // rows whose CB cut-off does not reach this group can be skipped: hi is non-decreasing, test the last row
-    if (hi[i_hi - 1] < k_base) return;
+    const int k_last = k_base + kWave - 1;
+    const int i_lo = row_begin + tile * qt;                                   // qt is a multiple of 16
+    const int i_hi = min(min(i_lo + qt, row_end), k_last);                    // need i < k for some lane
+    if (i_lo >= i_hi || k_last < z0) return;
+    if (hi[i_hi - 1] < k_base) return;                                        // hi is non-decreasing
 
-    const int k = k_base + lane;
+    __shared__ selhip_int2_t app_lds[kWavesPerBlock * kAppendCap];
+    WaveAppender app;
+    app.init(app_lds, wave, cand, cand_cap, &pc->n_candidates);
+    const int k = k_base + lane;                                              // < n_pad
     uint32_t c[NB];
 #pragma unroll
-    for (int b = 0; b < NB; ++b) c[b] = sigT[(long long)b * n_pad + k];         // k < n_pad always
+    for (int b = 0; b < NB; ++b) c[b] = sigT[(long long)b * n_pad + k];
 
-    for (int i = i_lo; i < i_hi; ++i) {
-        const uint32_t* __restrict__ q = sigQ + (long long)i * NB;               // wave-uniform address
-        u64 mask = 0;
+    for (int i16 = i_lo; i16 < i_hi; i16 += 16) {
+        const int qi = min(i16 + (lane & 15), n_pad - 1);
+        uint32_t qv[NB];
 #pragma unroll
-        for (int b = 0; b < NB; ++b) mask |= __ballot(c[b] == q[b]);
-        if (mask) {
-            const int lo = max(i + 1, z0);
-            const int hk = min(hi[i], n - 1);
-            if (((mask >> lane) & 1ull) && k >= lo && k <= hk) {
-                u64 idx = atomicAdd(&pc->n_candidates, 1ull);
-                if (idx < cand_cap) { cand[idx].x = i; cand[idx].y = k; }
-            }
-        }
+        for (int b = 0; b < NB; ++b) qv[b] = sigT[(long long)b * n_pad + qi];
+#define SELHIP_JQ(J) join_one_query<NB, J>(c, qv, i16 + J, i_hi, k, lane, z0, n, hi, app);
+        SELHIP_JQ(0) SELHIP_JQ(1) SELHIP_JQ(2) SELHIP_JQ(3) SELHIP_JQ(4) SELHIP_JQ(5) SELHIP_JQ(6) SELHIP_JQ(7)
+        SELHIP_JQ(8) SELHIP_JQ(9) SELHIP_JQ(10) SELHIP_JQ(11) SELHIP_JQ(12) SELHIP_JQ(13) SELHIP_JQ(14) SELHIP_JQ(15)
+#undef SELHIP_JQ
     }
+    app.flush(lane);
 }
 
 // verify_kernel: the literal smh_a on every candidate (one lane per candidate), survivors compacted.
@@ -451,7 +536,22 @@ void hll_union_hist_kernel(const uint8_t* __restrict__ hll, int p,
             const selhip_int2_t pr = pairs[j];
             const uint8_t* a = hll + (long long)pr.x * nreg;
             const uint8_t* b = hll + (long long)pr.y * nreg;
-            if (nreg >= 1024) {
+            if (nreg == 16384) {
+                // p = 14: both rows (2 x 16 KiB) are requested up front -- 32 x 16-B loads in flight per lane --
+                // before any LDS work starts; the kernel is bound by bytes in flight otherwise
+                const uint4* a4 = reinterpret_cast<const uint4*>(a);
+                const uint4* b4 = reinterpret_cast<const uint4*>(b);
+                uint4 xa[16], xb[16];
+#pragma unroll
+                for (int it = 0; it < 16; ++it) { xa[it] = a4[it * kWave + lane]; xb[it] = b4[it * kWave + lane]; }
+#pragma unroll
+                for (int it = 0; it < 16; ++it) {
+                    hist_add_word(col, max_u8x4(xa[it].x, xb[it].x));
+                    hist_add_word(col, max_u8x4(xa[it].y, xb[it].y));
+                    hist_add_word(col, max_u8x4(xa[it].z, xb[it].z));
+                    hist_add_word(col, max_u8x4(xa[it].w, xb[it].w));
+                }
+            } else if (nreg >= 1024) {
                 const uint4* a4 = reinterpret_cast<const uint4*>(a);
                 const uint4* b4 = reinterpret_cast<const uint4*>(b);
                 const int iters = (int)(nreg / (16 * kWave));
@@ -710,8 +810,8 @@ struct KernelTimer {
     long launches = 0;
 };
 
-enum { T_PREP = 0, T_STAGE1, T_HIST, T_SELECT, T_TOTAL, T_COUNT };
-const char* kTimerNames[T_COUNT] = {"prep", "stage1", "hist", "select", "total"};
+enum { T_PREP = 0, T_STAGE1, T_HIST, T_SELECT, T_TOTAL, T_SIGBUILD, T_JOIN, T_VERIFY, T_COUNT };
+const char* kTimerNames[T_COUNT] = {"prep", "stage1", "hist", "select", "total", "sigbuild", "join", "verify"};
 
 }  // namespace
 
@@ -871,10 +971,17 @@ bool sig_supported(int m, int n_rows, int n_bands) {
     return is_pow2(n_rows) && (n_bands == 8 || n_bands == 16 || n_bands == 32 || n_bands == 64 || n_bands == 128);
 }
 
+int env_int(const char* name, int dflt) {
+    const char* v = std::getenv(name);
+    return v && *v ? std::atoi(v) : dflt;
+}
+
 template <int NB>
 hipError_t launch_join(selhip_ctx* c, int n_pad, int rb, int re) {
     const int n = (int)c->n;
-    const int n_tiles = (re - rb + kJoinQT - 1) / kJoinQT;
+    int qt = std::max(16, env_int("SELHIP_JOIN_QT", 128));                            // development knob
+    qt = (qt + 15) / 16 * 16;
+    const int n_tiles = (re - rb + qt - 1) / qt;
     const int group_base = ((rb + 1) / kWave / kWavesPerBlock) * kWavesPerBlock;      // candidates k > row_begin
     const int n_groups = (n + kWave - 1) / kWave - group_base;
     const int n_gblocks = (n_groups + kWavesPerBlock - 1) / kWavesPerBlock;
@@ -882,7 +989,7 @@ hipError_t launch_join(selhip_ctx* c, int n_pad, int rb, int re) {
     const long long blocks = (long long)n_tiles * n_gblocks;
     if (blocks > 0x7FFFFFFFll) return hipErrorInvalidValue;
     hipLaunchKernelGGL((sig_join_kernel<NB>), dim3((unsigned)blocks), dim3(kBlock), 0, c->stream,
-                       c->sigQ.p, c->sigT.p, n, n_pad, c->hi.p, c->pc.p, rb, re, n_tiles, group_base,
+                       c->sigT.p, n, n_pad, c->hi.p, c->pc.p, rb, re, n_tiles, group_base, qt,
                        c->cand.p, (u64)c->cand.cap, c->pc.p);
     return hipGetLastError();
 }
@@ -891,6 +998,7 @@ hipError_t launch_stage1_sig(selhip_ctx* c, int n_rows, int n_bands, int rb, int
     const int n = (int)c->n;
     const int n_pad = ((n + kWave - 1) / kWave) * kWave;
     {
+        TimerScope t(c, T_SIGBUILD);
         const long long threads = n_rows <= kWave ? (long long)n * c->m : (long long)n * n_bands;
         hipLaunchKernelGGL(sig_build_kernel, dim3((unsigned)((threads + kBlock - 1) / kBlock)), dim3(kBlock), 0, c->stream,
                            c->d_aux, n, c->m, n_rows, n_bands, n_pad, c->sigQ.p, c->sigT.p);
@@ -898,6 +1006,8 @@ hipError_t launch_stage1_sig(selhip_ctx* c, int n_rows, int n_bands, int rb, int
         if (e != hipSuccess) return e;
     }
     hipError_t e = hipSuccess;
+    {
+    TimerScope t(c, T_JOIN);
     switch (n_bands) {
         case 8: e = launch_join<8>(c, n_pad, rb, re); break;
         case 16: e = launch_join<16>(c, n_pad, rb, re); break;
@@ -906,7 +1016,9 @@ hipError_t launch_stage1_sig(selhip_ctx* c, int n_rows, int n_bands, int rb, int
         case 128: e = launch_join<128>(c, n_pad, rb, re); break;
         default: return hipErrorInvalidValue;
     }
+    }
     if (e != hipSuccess) return e;
+    TimerScope t(c, T_VERIFY);
     hipLaunchKernelGGL(verify_kernel, dim3(1024), dim3(kBlock), 0, c->stream, c->d_aux, c->m, n_rows, n_bands,
                        c->cand.p, &c->pc.p->n_candidates, (u64)c->cand.cap, c->surv.p, (u64)c->surv.cap, c->pc.p);
     return hipGetLastError();
