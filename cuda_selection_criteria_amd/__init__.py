@@ -4,8 +4,8 @@ sanhue903/CUDA_Selection_Criteria: `selection` / `time_smh_cuda`).
 Python here is plumbing only (device memory via torch, torch.distributed for the multi-GPU gather,
 ctypes bindings); the product is csrc/ (HIP kernels + C ABI in include/selection_hip.h, C++ host code).
 """
-from ._lib import (ALGO_AUTO, ALGO_SIG, ALGO_STREAM, BANDING_CPU, BANDING_CUDA, FP_FMA, FP_STRICT,  # noqa: F401
-                   MODE_CB_SMH, MODE_SMH, SelhipError, hip_lib, host_lib)
+from ._lib import (ALGO_AUTO, ALGO_SIG, ALGO_STREAM, BANDING_CPU, BANDING_CUDA, CRIT_HLL_A, CRIT_HLL_A_SMH_A,  # noqa: F401
+                   CRIT_HLL_AN, CRIT_SMH_A, FP_FMA, FP_STRICT, MODE_CB_SMH, MODE_SMH, SelhipError, hip_lib, host_lib)
 from .selection import (PAIR_DTYPE, Selector, banding, format_lines, load_dataset, select_from_filelist,  # noqa: F401
                         sort_by_card)
 from .synth import SYNTH_CONFIGS, SynthConfig, synth_device, synth_host  # noqa: F401

@@ -42,6 +42,7 @@ class Synth(C.Structure):
 MODE_SMH, MODE_CB_SMH = 0, 1
 ALGO_AUTO, ALGO_STREAM, ALGO_SIG = 0, 1, 2
 FP_STRICT, FP_FMA = 0, 1
+CRIT_SMH_A, CRIT_HLL_A, CRIT_HLL_AN, CRIT_HLL_A_SMH_A = 0, 1, 2, 3
 BANDING_CPU, BANDING_CUDA = 0, 1
 
 _vp, _i, _i64, _d, _sz, _cp = C.c_void_p, C.c_int, C.c_int64, C.c_double, C.c_size_t, C.c_char_p
@@ -58,6 +59,9 @@ HIP_SYMBOLS = {
     "selhip_ctx_set_fp_mode": (_i, [_vp, _i]),
     "selhip_ctx_upload": (_i, [_vp, _vp, _vp, _vp, _i64, _i, _i]),
     "selhip_ctx_attach": (_i, [_vp, _vp, _vp, _vp, _i64, _i, _i]),
+    "selhip_ctx_upload_aux_hll": (_i, [_vp, _vp, _i]),
+    "selhip_ctx_attach_aux_hll": (_i, [_vp, _vp, _i]),
+    "selhip_ctx_set_criterion": (_i, [_vp, _i]),
     "selhip_hll_cards": (_i, [_vp, _vp, _i64, _i, _vp]),
     "selhip_ctx_get_cards": (_i, [_vp, _vp]),
     "selhip_ctx_run": (_i, [_vp, _i, _i, C.c_float, _i, _i, _i64, _i64]),

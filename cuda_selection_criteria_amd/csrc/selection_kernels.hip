@@ -54,6 +54,8 @@ struct PassCounters {
     u64 n_results;       // selected pairs appended (same convention)
     u64 n_evaluated;     // pairs inside the (triangular / CB-banded) pair space of this pass
     u64 n_candidates;    // ALGO_SIG: signature-join candidates
+    u64 n_aux_in;        // pairs handed to the auxiliary-HLL criterion (hll_a / hll_an)
+    u64 n_final;         // pairs handed to the final HLL-14 Jaccard stage
     int z0;              // first rank with e != 0
     int unsorted;        // set if cards are not ascending
     int pad[2];
@@ -515,12 +517,16 @@ __device__ __forceinline__ void hist_add_word(uint32_t* __restrict__ col, uint32
 __global__ __launch_bounds__(kBlock)
 void hll_union_hist_kernel(const uint8_t* __restrict__ hll, int p,
                            const selhip_int2_t* __restrict__ pairs, const u64* __restrict__ n_pairs_dev,
-                           u64 n_pairs_host, u64 cap, uint32_t* __restrict__ counts) {
+                           u64 n_pairs_host, u64 cap, uint32_t* __restrict__ counts,
+                           u64 chunk_off = 0, u64 chunk_len = ~0ull) {
     __shared__ uint32_t hist[kWavesPerBlock][64 * kWave];     // 64 KiB
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = threadIdx.x / kWave;
     u64 n_pairs = n_pairs_dev ? *n_pairs_dev : n_pairs_host;
     if (n_pairs > cap) n_pairs = cap;
+    // optional window [chunk_off, chunk_off + chunk_len) of the list; counts are indexed from the window start
+    n_pairs = n_pairs > chunk_off ? min(n_pairs - chunk_off, chunk_len) : 0;
+    pairs += chunk_off;
     const long long nreg = 1ll << p;
     uint32_t* my = hist[wave];
     uint32_t* col = my + lane;
@@ -602,11 +608,15 @@ void ertl_select_kernel(const uint32_t* __restrict__ counts, const u64* __restri
                         double* __restrict__ est,
                         const selhip_int2_t* __restrict__ pairs, const u64* __restrict__ ecard, double tau,
                         selhip_pair_t* __restrict__ results, u64 results_cap, PassCounters* __restrict__ pc,
-                        selhip_result_t* __restrict__ results_f32, int* __restrict__ out_count_i32) {
+                        selhip_result_t* __restrict__ results_f32, int* __restrict__ out_count_i32,
+                        u64 chunk_off, u64 chunk_len) {
     __shared__ uint32_t lds[64 * 65];
     const int lane = threadIdx.x;
     u64 n = n_dev ? *n_dev : n_host;
     if (n > cap) n = cap;
+    n = n > chunk_off ? min(n - chunk_off, chunk_len) : 0;       // window of the list; counts indexed from its start
+    if (pairs) pairs += chunk_off;
+    if (est) est += chunk_off;
     for (u64 base = (u64)blockIdx.x * kWave; base < n; base += (u64)gridDim.x * kWave) {
         __syncthreads();
         // row r of the tile = histogram base+r; lane = bin -> coalesced 256 B reads
@@ -638,6 +648,85 @@ void ertl_select_kernel(const uint32_t* __restrict__ counts, const u64* __restri
             }
         }
     }
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// Auxiliary-HLL criteria (src/selection.cpp:152-173 hll_a, :206-227 hll_an; criteria_sketch.hpp:22-64).
+// enum_pairs_kernel lists the (CB-pruned) pair space of the rows explicitly -- only used when hll_a / hll_an
+// is the FIRST criterion; in the two-stage form (BASELINE config 5) the cheap smh_a join runs first and the
+// auxiliary criterion sees its survivors only: the selected set is the intersection either way.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock)
+void enum_pairs_kernel(int n, const int* __restrict__ hi, const PassCounters* __restrict__ pc_in,
+                       int row_begin, int row_end, int n_rows_grid,
+                       selhip_int2_t* __restrict__ out, u64 out_cap, PassCounters* __restrict__ pc) {
+    __shared__ selhip_int2_t app_lds[kWavesPerBlock * kAppendCap];
+    const int i = row_begin + (int)(blockIdx.x % n_rows_grid);
+    const int chunk = blockIdx.x / n_rows_grid;
+    if (i >= row_end) return;
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
+    const int kmin = max(i + 1, pc_in->z0);
+    const int k = kmin + chunk * kBlock + (int)threadIdx.x;
+    WaveAppender app;
+    app.init(app_lds, wave, out, out_cap, &pc->n_aux_in);
+    app.push(k <= hi[i] && k < n, i, k, lane);
+    app.flush(lane);
+}
+
+// aux_filter_kernel<FMA, CRIT>: one LANE per pair; counts = union histogram of the two AUXILIARY sketches.
+//   CRIT 1 (hll_a):  t_hat = (size_t)U;  t+ = t_hat / (1 + Z*sigma_p);  K+ = ((1+gamma)*e_k - t+)/t+ >= tau
+//   CRIT 2 (hll_an): J = ((double)(e_i+e_k) - U)/U;  C = min(1, (1+Z*sigma_p)*e_k/U) * (1+gamma) * S;  J + C >= tau
+// zs = (double)(float)(Z*sigma_p) and S (= zs for order_n = 1) are computed on the host in float/double exactly as
+// criteria_sketch.hpp:7-20,25-31,39-40 do.  FMA flavour: g++ fuses (1+gamma)*card_B - t_hat_mas (criteria_sketch.hpp:41).
+template <bool FMA, int CRIT>
+__global__ __launch_bounds__(kWave)
+void aux_filter_kernel(const uint32_t* __restrict__ counts, const selhip_int2_t* __restrict__ pairs,
+                       const u64* __restrict__ n_dev, u64 chunk_off, u64 chunk_len, u64 cap,
+                       int p_aux, double relerr_scaled, const u64* __restrict__ ecard, double tau,
+                       double zs, double S_sum,
+                       selhip_int2_t* __restrict__ out, u64 out_cap, u64* __restrict__ out_count) {
+    __shared__ uint32_t lds[64 * 65];
+    __shared__ selhip_int2_t app_lds[kAppendCap];
+    const int lane = threadIdx.x;
+    u64 total = *n_dev;
+    if (total > cap) total = cap;
+    const u64 n = total > chunk_off ? min(total - chunk_off, chunk_len) : 0;     // pairs of this chunk
+    WaveAppender app;
+    app.init(app_lds, 0, out, out_cap, out_count);
+    for (u64 base = (u64)blockIdx.x * kWave; base < n; base += (u64)gridDim.x * kWave) {
+        __syncthreads();
+        for (int r = 0; r < kWave; ++r) {
+            u64 j = base + r;
+            lds[lane * 65 + r] = (j < n) ? counts[j * 64 + lane] : (lane == 0 ? (1u << p_aux) : 0u);
+        }
+        __syncthreads();
+        const u64 j = base + lane;
+        LdsCounts c{lds + lane};
+        const double U = selhip::ertl_ml_estimate<FMA>(c, (unsigned)p_aux, (unsigned)(64 - p_aux), relerr_scaled);
+        bool sel = false;
+        selhip_int2_t pr{0, 0};
+        if (j < n) {
+            pr = pairs[chunk_off + j];
+            const u64 ea = ecard[pr.x], eb = ecard[pr.y];
+            const double gamma = (double)ea / (double)eb;                         // criteria_sketch.hpp:24,38
+            if constexpr (CRIT == 1) {
+                const double t_hat = (double)(u64)(long long)U;                   // size_t t_hat = union_size()  (:61)
+                const double t_mas = t_hat / (1.0 + zs);                          // :40
+                const double K = selhip::muladd<FMA>(1.0 + gamma, (double)eb, -t_mas) / t_mas;   // :41
+                sel = K >= tau;                                                   // :63
+            } else {
+                const double J = ((double)(ea + eb) - U) / U;                     // :55
+                const double candv = (1.0 + zs) * (double)eb / U;                 // :32
+                const double minimo = candv < 1.0 ? candv : 1.0;                  // std::min(1.0, .)
+                const double C = minimo * (1 + gamma) * S_sum;                    // :33
+                sel = (J + C) >= tau;                                             // :57
+            }
+        }
+        app.push(sel, pr.x, pr.y, lane);
+    }
+    app.flush(lane);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -810,8 +899,8 @@ struct KernelTimer {
     long launches = 0;
 };
 
-enum { T_PREP = 0, T_STAGE1, T_HIST, T_SELECT, T_TOTAL, T_SIGBUILD, T_JOIN, T_VERIFY, T_COUNT };
-const char* kTimerNames[T_COUNT] = {"prep", "stage1", "hist", "select", "total", "sigbuild", "join", "verify"};
+enum { T_PREP = 0, T_STAGE1, T_HIST, T_SELECT, T_TOTAL, T_SIGBUILD, T_JOIN, T_VERIFY, T_AUX, T_COUNT };
+const char* kTimerNames[T_COUNT] = {"prep", "stage1", "hist", "select", "total", "sigbuild", "join", "verify", "aux"};
 
 }  // namespace
 
@@ -840,7 +929,12 @@ struct selhip_ctx {
     DevBuf<uint32_t> counts;
     DevBuf<selhip_pair_t> results;
     DevBuf<selhip_int2_t> self_pairs;
-    DevBuf<selhip_int2_t> cand;         // ALGO_SIG: signature-join candidates
+    DevBuf<selhip_int2_t> cand;         // ALGO_SIG: signature-join candidates; aux criteria: enumerated pairs
+    DevBuf<selhip_int2_t> fin;          // aux criteria: pairs that passed hll_a / hll_an
+    const uint8_t* d_aux_hll = nullptr; // auxiliary HLL registers [n][1 << p_aux]
+    DevBuf<uint8_t> own_aux_hll;
+    int p_aux = 0;
+    int criterion = 0;
     DevBuf<uint32_t> sigQ, sigT;        // ALGO_SIG: band signatures, query-major / band-major
     PassCounters* h_pc = nullptr;       // pinned host mirror
 
@@ -1028,14 +1122,14 @@ template <int MODE>
 hipError_t launch_select(bool fma, hipStream_t st, unsigned grid, const uint32_t* counts, const u64* n_dev, u64 n_host,
                          u64 cap, int p, double* est, const selhip_int2_t* pairs, const u64* ecard, double tau,
                          selhip_pair_t* results, u64 results_cap, PassCounters* pc,
-                         selhip_result_t* rf32, int* out_count) {
+                         selhip_result_t* rf32, int* out_count, u64 chunk_off = 0, u64 chunk_len = ~0ull) {
     const double rs = relerr_scaled_for(p);
     if (fma)
         hipLaunchKernelGGL((ertl_select_kernel<true, MODE>), dim3(grid), dim3(kWave), 0, st, counts, n_dev, n_host, cap,
-                           p, rs, est, pairs, ecard, tau, results, results_cap, pc, rf32, out_count);
+                           p, rs, est, pairs, ecard, tau, results, results_cap, pc, rf32, out_count, chunk_off, chunk_len);
     else
         hipLaunchKernelGGL((ertl_select_kernel<false, MODE>), dim3(grid), dim3(kWave), 0, st, counts, n_dev, n_host, cap,
-                           p, rs, est, pairs, ecard, tau, results, results_cap, pc, rf32, out_count);
+                           p, rs, est, pairs, ecard, tau, results, results_cap, pc, rf32, out_count, chunk_off, chunk_len);
     return hipGetLastError();
 }
 
@@ -1061,10 +1155,48 @@ int compute_cards(selhip_ctx* c, const uint8_t* d_hll, int64_t n, int p, double*
     return SELHIP_OK;
 }
 
+// criteria_sketch.hpp:7-20 sigma(p): a double expression narrowed to float by the return type
+float sigma_p_of(int p) {
+    switch (p) {
+        case 4: return (float)(1.106 / std::sqrt((double)(1 << p)));
+        case 5: return (float)(1.07 / std::sqrt((double)(1 << p)));
+        case 6: return (float)(1.054 / std::sqrt((double)(1 << p)));
+        case 7: return (float)(1.046 / std::sqrt((double)(1 << p)));
+    }
+    return (float)(1.039 / std::sqrt((double)(1 << p)));
+}
+
+// upper bound of the pair space of rows [rb, re): the triangle (CB can only shrink it)
+long long pair_bound(long long n, long long rb, long long re) {
+    long long cnt = 0;
+    // sum_{i=rb}^{re-1} (n-1-i)
+    const long long rows = re - rb;
+    cnt = rows * (n - 1) - (rb + re - 1) * rows / 2;
+    return cnt < 0 ? 0 : cnt;
+}
+
+template <int CRIT>
+hipError_t launch_aux_filter(selhip_ctx* c, const selhip_int2_t* list, const u64* n_dev, u64 off, u64 len, u64 cap, double tau) {
+    const float Z = 1.96f;                                   // z_score, selection.cpp:76
+    const float zs_f = Z * sigma_p_of(c->p_aux);             // float * float (criteria_sketch.hpp:29,40)
+    const double zs = (double)zs_f;
+    const double S_sum = zs;                                 // order_n = 1 (selection.cpp:77): S = Z*sigma_p
+    const double rs = relerr_scaled_for(c->p_aux);
+    const unsigned grid = 2048;
+    if (c->fp_mode == SELHIP_FP_FMA)
+        hipLaunchKernelGGL((aux_filter_kernel<true, CRIT>), dim3(grid), dim3(kWave), 0, c->stream, c->counts.p, list, n_dev, off, len, cap,
+                           c->p_aux, rs, c->ecard.p, tau, zs, S_sum, c->fin.p, (u64)c->fin.cap, &c->pc.p->n_final);
+    else
+        hipLaunchKernelGGL((aux_filter_kernel<false, CRIT>), dim3(grid), dim3(kWave), 0, c->stream, c->counts.p, list, n_dev, off, len, cap,
+                           c->p_aux, rs, c->ecard.p, tau, zs, S_sum, c->fin.p, (u64)c->fin.cap, &c->pc.p->n_final);
+    return hipGetLastError();
+}
+
 int enqueue_pass(selhip_ctx* c) {
     const int n = (int)c->n;
     const int rb = (int)c->row_begin, re = (int)c->row_end;
     const double tau = (double)c->tau_f;            // float threshold widened, selection.cpp:81,164
+    const int crit = c->criterion;
     TimerScope total(c, T_TOTAL);
     HIPCHK(&c->err, hipMemsetAsync(c->pc.p, 0, sizeof(PassCounters), c->stream));
     {
@@ -1076,7 +1208,11 @@ int enqueue_pass(selhip_ctx* c) {
                            c->d_cards, n, tau, c->mode == SELHIP_MODE_CB_SMH ? 1 : 0, rb, re, c->ecard.p, c->hi.p, c->pc.p);
         HIPCHK(&c->err, hipGetLastError());
     }
-    {
+    // ---- first criterion: smh_a (stream / signature join) or the explicit pair space for hll_a / hll_an
+    const selhip_int2_t* final_list = c->surv.p;
+    const u64* final_count = &c->pc.p->n_survivors;
+    u64 final_cap = (u64)c->surv.cap;
+    if (crit == SELHIP_CRIT_SMH_A || crit == SELHIP_CRIT_HLL_A_SMH_A) {
         TimerScope t(c, T_STAGE1);
         const bool use_sig = (c->algo == SELHIP_ALGO_SIG || c->algo == SELHIP_ALGO_AUTO) && sig_supported(c->m, c->n_rows, c->n_bands);
         if (c->algo == SELHIP_ALGO_SIG && !use_sig) {
@@ -1085,18 +1221,51 @@ int enqueue_pass(selhip_ctx* c) {
         }
         if (use_sig) HIPCHK(&c->err, launch_stage1_sig(c, c->n_rows, c->n_bands, rb, re));
         else         HIPCHK(&c->err, launch_stage1(c, c->n_rows, c->n_bands, rb, re));
+    } else {
+        TimerScope t(c, T_STAGE1);
+        const int rows = re - rb;
+        const long long blocks = (long long)rows * ((n + kBlock - 1) / kBlock);
+        if (blocks > 0x7FFFFFFFll) { set_err(&c->err, "row range too large"); return SELHIP_E_BADARG; }
+        if (blocks > 0) {
+            hipLaunchKernelGGL(enum_pairs_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, c->stream, n, c->hi.p, c->pc.p,
+                               rb, re, rows, c->cand.p, (u64)c->cand.cap, c->pc.p);
+            HIPCHK(&c->err, hipGetLastError());
+        }
     }
-    {
-        TimerScope t(c, T_HIST);
-        hipLaunchKernelGGL(hll_union_hist_kernel, dim3(2048), dim3(kBlock), 0, c->stream,
-                           c->d_hll, c->p, c->surv.p, &c->pc.p->n_survivors, (u64)0, (u64)c->surv.cap, c->counts.p);
-        HIPCHK(&c->err, hipGetLastError());
+    // ---- auxiliary-HLL criterion (hll_a / hll_an), in windows of the counts buffer
+    if (crit != SELHIP_CRIT_SMH_A) {
+        TimerScope t(c, T_AUX);
+        const selhip_int2_t* list = crit == SELHIP_CRIT_HLL_A_SMH_A ? c->surv.p : c->cand.p;
+        const u64* n_dev = crit == SELHIP_CRIT_HLL_A_SMH_A ? &c->pc.p->n_survivors : &c->pc.p->n_aux_in;
+        const u64 cap = crit == SELHIP_CRIT_HLL_A_SMH_A ? (u64)c->surv.cap : (u64)c->cand.cap;
+        const u64 window = (u64)c->counts.cap / 64;
+        const u64 bound = crit == SELHIP_CRIT_HLL_A_SMH_A ? cap : std::min<u64>(cap, (u64)pair_bound(n, rb, re));
+        for (u64 off = 0; off < bound; off += window) {
+            hipLaunchKernelGGL(hll_union_hist_kernel, dim3(2048), dim3(kBlock), 0, c->stream,
+                               c->d_aux_hll, c->p_aux, list, n_dev, (u64)0, cap, c->counts.p, off, window);
+            HIPCHK(&c->err, hipGetLastError());
+            if (crit == SELHIP_CRIT_HLL_AN) HIPCHK(&c->err, launch_aux_filter<2>(c, list, n_dev, off, window, cap, tau));
+            else                            HIPCHK(&c->err, launch_aux_filter<1>(c, list, n_dev, off, window, cap, tau));
+        }
+        final_list = c->fin.p;
+        final_count = &c->pc.p->n_final;
+        final_cap = (u64)c->fin.cap;
     }
+    // ---- final criterion: HLL-14 union estimate + Jaccard (selection.cpp:286-288), windows of the counts buffer
     {
-        TimerScope t(c, T_SELECT);
-        HIPCHK(&c->err, launch_select<1>(c->fp_mode == SELHIP_FP_FMA, c->stream, 4096, c->counts.p, &c->pc.p->n_survivors, 0,
-                                         (u64)c->surv.cap, c->p, nullptr, c->surv.p, c->ecard.p, tau,
-                                         c->results.p, (u64)c->results.cap, c->pc.p, nullptr, nullptr));
+        const u64 window = (u64)c->counts.cap / 64;
+        for (u64 off = 0; off < final_cap; off += window) {
+            {
+                TimerScope t(c, T_HIST);
+                hipLaunchKernelGGL(hll_union_hist_kernel, dim3(2048), dim3(kBlock), 0, c->stream,
+                                   c->d_hll, c->p, final_list, final_count, (u64)0, final_cap, c->counts.p, off, window);
+                HIPCHK(&c->err, hipGetLastError());
+            }
+            TimerScope t(c, T_SELECT);
+            HIPCHK(&c->err, launch_select<1>(c->fp_mode == SELHIP_FP_FMA, c->stream, 4096, c->counts.p, final_count, 0,
+                                             final_cap, c->p, nullptr, final_list, c->ecard.p, tau,
+                                             c->results.p, (u64)c->results.cap, c->pc.p, nullptr, nullptr, off, window));
+        }
     }
     HIPCHK(&c->err, hipMemcpyAsync(c->h_pc, c->pc.p, sizeof(PassCounters), hipMemcpyDeviceToHost, c->stream));
     return SELHIP_OK;
@@ -1108,6 +1277,16 @@ int ensure_scratch(selhip_ctx* c, size_t surv_cap, size_t res_cap) {
     HIPCHK(&c->err, c->pc.ensure(1));
     HIPCHK(&c->err, c->surv.ensure(surv_cap));
     HIPCHK(&c->err, c->cand.ensure(surv_cap));
+    if (c->criterion != SELHIP_CRIT_SMH_A) HIPCHK(&c->err, c->fin.ensure(surv_cap));
+    if (c->criterion == SELHIP_CRIT_HLL_A || c->criterion == SELHIP_CRIT_HLL_AN) {
+        // the explicit pair space of the row range is materialised (8 B per pair)
+        const long long bound = pair_bound(c->n, c->row_begin, c->row_end);
+        if (bound > (1ll << 28)) {
+            set_err(&c->err, "hll_a/hll_an as first criterion enumerates %lld pairs for this row range; pass sub-ranges of rows (<= 2^28 pairs each)", bound);
+            return SELHIP_E_BADARG;
+        }
+        HIPCHK(&c->err, c->cand.ensure((size_t)bound + 1024));
+    }
     {
         const size_t n_pad = (((size_t)c->n + kWave - 1) / kWave) * kWave;
         const size_t nb = (size_t)std::max(c->n_bands, 1);
@@ -1116,7 +1295,8 @@ int ensure_scratch(selhip_ctx* c, size_t surv_cap, size_t res_cap) {
             HIPCHK(&c->err, c->sigT.ensure(n_pad * nb));
         }
     }
-    HIPCHK(&c->err, c->counts.ensure(std::max(c->surv.cap, (size_t)c->n) * 64));
+    // histogram scratch: 256 B per pair, at most 1 Mi pairs per window (256 MiB)
+    HIPCHK(&c->err, c->counts.ensure(std::min<size_t>(std::max(c->surv.cap, (size_t)c->n), (size_t)1 << 20) * 64));
     HIPCHK(&c->err, c->results.ensure(res_cap));
     if (!c->h_pc) HIPCHK(&c->err, hipHostMalloc((void**)&c->h_pc, sizeof(PassCounters), hipHostMallocDefault));
     return SELHIP_OK;
@@ -1171,7 +1351,7 @@ void selhip_ctx_destroy(selhip_ctx* c) {
     c->own_hll.release(); c->own_aux.release(); c->own_cards.release();
     c->ecard.release(); c->hi.release(); c->pc.release(); c->surv.release();
     c->counts.release(); c->results.release(); c->self_pairs.release();
-    c->cand.release(); c->sigQ.release(); c->sigT.release();
+    c->cand.release(); c->sigQ.release(); c->sigT.release(); c->fin.release(); c->own_aux_hll.release();
     if (c->h_pc) (void)hipHostFree(c->h_pc);
     delete c;
 }
@@ -1185,6 +1365,30 @@ int selhip_ctx_set_stream(selhip_ctx* c, void* hip_stream) {
 int selhip_ctx_set_fp_mode(selhip_ctx* c, int fp_mode) {
     if (!c || (fp_mode != SELHIP_FP_FMA && fp_mode != SELHIP_FP_STRICT)) return SELHIP_E_BADARG;
     c->fp_mode = fp_mode;
+    return SELHIP_OK;
+}
+
+int selhip_ctx_set_criterion(selhip_ctx* c, int criterion) {
+    if (!c || criterion < SELHIP_CRIT_SMH_A || criterion > SELHIP_CRIT_HLL_A_SMH_A) return SELHIP_E_BADARG;
+    c->criterion = criterion;
+    return SELHIP_OK;
+}
+
+int selhip_ctx_upload_aux_hll(selhip_ctx* c, const uint8_t* h_aux_hll, int p_aux) {
+    if (!c || !h_aux_hll || p_aux < 4 || p_aux > 16) return SELHIP_E_BADARG;
+    if (!c->d_hll && c->n) { set_err(&c->err, "upload the primary sketches first"); return SELHIP_E_STATE; }
+    HIPCHK(&c->err, hipSetDevice(c->device));
+    const size_t bytes = (size_t)c->n << p_aux;
+    HIPCHK(&c->err, c->own_aux_hll.ensure(bytes ? bytes : 1));
+    if (bytes) HIPCHK(&c->err, hipMemcpyAsync(c->own_aux_hll.p, h_aux_hll, bytes, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(&c->err, hipStreamSynchronize(c->stream));
+    c->d_aux_hll = c->own_aux_hll.p; c->p_aux = p_aux;
+    return SELHIP_OK;
+}
+
+int selhip_ctx_attach_aux_hll(selhip_ctx* c, const uint8_t* d_aux_hll, int p_aux) {
+    if (!c || !d_aux_hll || p_aux < 4 || p_aux > 16) return SELHIP_E_BADARG;
+    c->d_aux_hll = d_aux_hll; c->p_aux = p_aux;
     return SELHIP_OK;
 }
 
@@ -1235,6 +1439,7 @@ int selhip_ctx_upload(selhip_ctx* c, const uint8_t* h_hll, const uint64_t* h_aux
         HIPCHK(&c->err, hipMemcpyAsync(c->own_aux.p, h_aux, (size_t)n * m * 8, hipMemcpyHostToDevice, c->stream));
     }
     c->d_hll = c->own_hll.p; c->d_aux = (const u64*)c->own_aux.p; c->owns_sketches = true;
+    c->d_aux_hll = nullptr; c->p_aux = 0;
     return after_sketches(c, h_cards, true);
 }
 
@@ -1248,6 +1453,7 @@ int selhip_ctx_attach(selhip_ctx* c, const uint8_t* d_hll, const uint64_t* d_aux
     if (((uintptr_t)d_hll & 15) || ((uintptr_t)d_aux & 15)) { set_err(&c->err, "sketch pointers must be 16-byte aligned"); return SELHIP_E_BADARG; }
     c->n = n; c->m = m; c->p = p_hll; c->have_run = false; c->pending = false;
     c->d_hll = d_hll; c->d_aux = (const u64*)d_aux; c->owns_sketches = false;
+    c->d_aux_hll = nullptr; c->p_aux = 0;
     return after_sketches(c, d_cards, false);
 }
 
@@ -1275,7 +1481,12 @@ int selhip_ctx_run_async(selhip_ctx* c, int mode, int algo, float tau_f, int n_r
     if (!c->d_aux && c->n) { set_err(&c->err, "run before upload/attach"); return SELHIP_E_STATE; }
     if (mode != SELHIP_MODE_SMH && mode != SELHIP_MODE_CB_SMH) { set_err(&c->err, "bad mode %d", mode); return SELHIP_E_BADARG; }
     if (algo != SELHIP_ALGO_AUTO && algo != SELHIP_ALGO_STREAM && algo != SELHIP_ALGO_SIG) { set_err(&c->err, "bad algo %d", algo); return SELHIP_E_BADARG; }
-    if (n_rows <= 0 || n_bands <= 0 || (long long)n_rows * n_bands != c->m) {
+    if (c->criterion != SELHIP_CRIT_SMH_A && !c->d_aux_hll && c->n) {
+        set_err(&c->err, "criterion %d needs auxiliary HLL sketches (selhip_ctx_upload_aux_hll)", c->criterion);
+        return SELHIP_E_STATE;
+    }
+    const bool needs_smh = c->criterion == SELHIP_CRIT_SMH_A || c->criterion == SELHIP_CRIT_HLL_A_SMH_A;
+    if (needs_smh && (n_rows <= 0 || n_bands <= 0 || (long long)n_rows * n_bands != c->m)) {
         // criteria_sketch.hpp:67-70: the reference prints an error and selects nothing; the ABI reports it
         set_err(&c->err, "n_rows*n_bands (%d*%d) != m (%d)", n_rows, n_bands, c->m);
         return SELHIP_E_BADARG;
@@ -1309,6 +1520,8 @@ int selhip_ctx_finish(selhip_ctx* c) {
         size_t surv_cap = c->surv.cap, res_cap = c->results.cap;
         if (pc.n_survivors > c->surv.cap) { surv_cap = (size_t)(pc.n_survivors + pc.n_survivors / 8 + 1024); grow = true; }
         if (pc.n_candidates > c->cand.cap) { surv_cap = std::max(surv_cap, (size_t)(pc.n_candidates + pc.n_candidates / 8 + 1024)); grow = true; }
+        if (c->criterion != SELHIP_CRIT_SMH_A && pc.n_final > c->fin.cap) { surv_cap = std::max(surv_cap, (size_t)(pc.n_final + pc.n_final / 8 + 1024)); grow = true; }
+        if (pc.n_aux_in > c->cand.cap) { c->pending = false; set_err(&c->err, "internal: enumerated pair list overflow"); return SELHIP_E_OVERFLOW; }
         if (pc.n_results > c->results.cap) { res_cap = (size_t)(pc.n_results + pc.n_results / 8 + 1024); grow = true; }
         if (!grow) {
             c->last = pc; c->pending = false; c->have_run = true;
@@ -1338,7 +1551,7 @@ int selhip_ctx_stats(const selhip_ctx* c, int64_t stats[4]) {
     if (!c || !stats) return SELHIP_E_BADARG;
     if (!c->have_run) return SELHIP_E_STATE;
     stats[0] = (int64_t)c->last.n_evaluated;
-    stats[1] = (int64_t)c->last.n_survivors;
+    stats[1] = (int64_t)(c->criterion == SELHIP_CRIT_SMH_A ? c->last.n_survivors : c->last.n_final);
     stats[2] = (int64_t)c->last.n_results;
     stats[3] = (int64_t)(c->last.n_candidates ? c->last.n_candidates : c->last.n_survivors);
     return SELHIP_OK;

@@ -11,7 +11,8 @@ from typing import Optional, Sequence, Tuple
 import numpy as np
 
 from . import _lib
-from ._lib import (ALGO_AUTO, BANDING_CPU, FP_FMA, MODE_CB_SMH, Pair, check, hip_lib, host_lib)
+from ._lib import (ALGO_AUTO, BANDING_CPU, CRIT_HLL_A, CRIT_HLL_AN, CRIT_HLL_A_SMH_A, CRIT_SMH_A, FP_FMA, MODE_CB_SMH, Pair,
+                   check, hip_lib, host_lib)
 
 # layout of selhip_pair_t {int32 i, k; double jaccard}
 PAIR_DTYPE = np.dtype([("i", "<i4"), ("k", "<i4"), ("jaccard", "<f8")], align=True)
@@ -141,6 +142,21 @@ class Selector:
         self._keep = (hll_t, aux_t, cards_t)
         self.n, self.m = n, m
 
+    def upload_aux_hll(self, aux_hll: np.ndarray, p_aux: int):
+        """auxiliary HLL sketches (.hll_<p> files) for the hll_a / hll_an criteria, rank order"""
+        aux_hll = np.ascontiguousarray(aux_hll, dtype=np.uint8)
+        assert aux_hll.shape == (self.n, 1 << p_aux)
+        check(self._lib.selhip_ctx_upload_aux_hll(self._ctx, aux_hll.ctypes.data, p_aux), self._ctx)
+
+    def attach_aux_hll(self, aux_hll_t, p_aux: int):
+        assert aux_hll_t.is_cuda and aux_hll_t.is_contiguous() and tuple(aux_hll_t.shape) == (self.n, 1 << p_aux)
+        check(self._lib.selhip_ctx_attach_aux_hll(self._ctx, aux_hll_t.data_ptr(), p_aux), self._ctx)
+        self._keep_aux = aux_hll_t
+
+    def set_criterion(self, criterion: int):
+        check(self._lib.selhip_ctx_set_criterion(self._ctx, criterion), self._ctx)
+        self.criterion = criterion
+
     def cards(self) -> np.ndarray:
         out = np.empty(self.n, dtype=np.float64)
         check(self._lib.selhip_ctx_get_cards(self._ctx, out.ctypes.data), self._ctx)
@@ -150,7 +166,7 @@ class Selector:
     def run(self, tau: float, mode: int = MODE_CB_SMH, n_rows: Optional[int] = None, n_bands: Optional[int] = None,
             rows: Optional[Tuple[int, int]] = None, algo: int = ALGO_AUTO, fetch: bool = True):
         if n_rows is None or n_bands is None:
-            n_rows, n_bands = banding(self.m, tau)
+            n_rows, n_bands = banding(self.m, tau) if self.m else (1, 1)
         rb, re = rows if rows is not None else (0, self.n)
         check(self._lib.selhip_ctx_run(self._ctx, mode, algo, np.float32(tau), n_rows, n_bands, rb, re), self._ctx)
         return self.fetch() if fetch else None
@@ -199,12 +215,23 @@ class Selector:
 
 
 def select_from_filelist(list_file: str, tau: float, aux_bytes: int, mode: int = MODE_CB_SMH, device: int = 0,
-                         fp_mode: int = FP_FMA, algo: int = ALGO_AUTO) -> str:
-    """The whole of selection_cuda.cpp main(): returns the text the CPU reference prints."""
-    m = aux_bytes // 8
-    ds = load_dataset(list_file, m, 0, fp_mode)
-    n_rows, n_bands = banding(m, tau)
+                         fp_mode: int = FP_FMA, algo: int = ALGO_AUTO, criterion: str = "smh_a") -> str:
+    """The whole of selection_cuda.cpp main() (criterion smh_a) -- and of selection.cpp's hll_a / hll_an
+    branches (:122-227): returns the text the CPU reference prints for `-c criterion -a aux_bytes -h tau`."""
+    if criterion == "smh_a":
+        m, p_aux, crit = aux_bytes // 8, 0, CRIT_SMH_A                       # selection.cpp:231
+    elif criterion in ("hll_a", "hll_an"):
+        m, p_aux = 0, (aux_bytes & -aux_bytes).bit_length() - 1               # __builtin_ctz(aux_bytes), selection.cpp:125
+        crit = CRIT_HLL_A if criterion == "hll_a" else CRIT_HLL_AN
+    else:
+        raise ValueError("Option -c invalid. The accepted criteria are hll_a, hll_an and smh_a.")
+    ds = load_dataset(list_file, m, p_aux, fp_mode)
+    n_rows, n_bands = banding(m, tau) if m else (1, 1)
     with Selector(device, fp_mode) as sel:
-        sel.upload(ds.hll, ds.aux, ds.cards)
+        aux = ds.aux if m else np.zeros((len(ds.names), 1), dtype=np.uint64)
+        sel.upload(ds.hll, aux, ds.cards)
+        if p_aux:
+            sel.upload_aux_hll(ds.aux_hll, p_aux)
+        sel.set_criterion(crit)
         pairs = sel.run(tau, mode, n_rows, n_bands, algo=algo)
     return format_lines(ds.names, pairs)

@@ -56,6 +56,18 @@ typedef struct { int32_t i, k; double jaccard; } selhip_pair_t;
 #define SELHIP_ALGO_STREAM   1     /* full m-bucket compare, candidates streamed row-major, query tile in LDS */
 #define SELHIP_ALGO_SIG      2     /* 32-bit band signatures joined all-pairs, exact verify of candidates  */
 
+/* selection criterion applied before the final HLL-14 Jaccard test (src/selection.cpp -c ...):
+ *   SMH_A        src/selection.cpp:228-291   (the north_star path)
+ *   HLL_A        src/selection.cpp:122-173   auxiliary HLL p = ctz(aux_bytes), criteria_sketch.hpp:36-43,60-64
+ *   HLL_AN       src/selection.cpp:175-227   criteria_sketch.hpp:22-34,52-58 (order_n = 1, Z = 1.96)
+ *   HLL_A_SMH_A  both hll_a and smh_a must select the pair (BASELINE.json config 5: "hll_a prefilter +
+ *                smh_a two-stage criterion"); evaluated smh_a first, hll_a on its survivors -- the selected
+ *                set is the intersection either way */
+#define SELHIP_CRIT_SMH_A        0
+#define SELHIP_CRIT_HLL_A        1
+#define SELHIP_CRIT_HLL_AN       2
+#define SELHIP_CRIT_HLL_A_SMH_A  3
+
 /* estimator arithmetic flavour (see csrc/ertl_mle.hpp) */
 #define SELHIP_FP_FMA        1     /* = reference built by its Makefile on an FMA-capable x86 host (default) */
 #define SELHIP_FP_STRICT     0     /* = reference built with -ffp-contract=off                              */
@@ -110,6 +122,14 @@ int selhip_ctx_upload(selhip_ctx* ctx, const uint8_t* h_hll, const uint64_t* h_a
 int selhip_ctx_attach(selhip_ctx* ctx, const uint8_t* d_hll, const uint64_t* d_aux, const double* d_cards,
                       int64_t n_genomes, int m, int p_hll);
 
+/* Auxiliary HLL sketches (the .hll_<p> files, rank order, [n][1 << p_aux] u8) for the hll_a / hll_an criteria;
+ * call after upload/attach of the primary sketches.  attach: device pointer owned by the caller. */
+int selhip_ctx_upload_aux_hll(selhip_ctx* ctx, const uint8_t* h_aux_hll, int p_aux);
+int selhip_ctx_attach_aux_hll(selhip_ctx* ctx, const uint8_t* d_aux_hll, int p_aux);
+/* criterion used by the following selhip_ctx_run* calls (default SELHIP_CRIT_SMH_A); n_rows/n_bands are
+ * ignored by HLL_A / HLL_AN */
+int selhip_ctx_set_criterion(selhip_ctx* ctx, int criterion);
+
 /* report() of every genome (Ertl-MLE, hll.h:834-837,862) computed on the device: d_cards_out[n]. */
 int selhip_hll_cards(selhip_ctx* ctx, const uint8_t* d_hll, int64_t n_genomes, int p, double* d_cards_out);
 /* copies the context's cardinalities to the host */
@@ -128,7 +148,7 @@ int selhip_ctx_finish(selhip_ctx* ctx);
 
 /* statistics of the last finished run:
  *   stats[0] pairs evaluated by the smh_a predicate (after e_k==0 / CB pruning)
- *   stats[1] stage-1 survivors (pairs with a fully equal band)
+ *   stats[1] pairs that passed the auxiliary criterion/criteria (smh_a: pairs with a fully equal band)
  *   stats[2] selected pairs (J >= tau)
  *   stats[3] candidates produced by the signature join (ALGO_SIG; = stats[1] for ALGO_STREAM) */
 int selhip_ctx_stats(const selhip_ctx* ctx, int64_t stats[4]);

@@ -173,7 +173,9 @@ double orc_kota_mas(size_t card_a, size_t card_b, double t_hat, int p, float Z)
     float sigma_p = orc_sigma(p);
     float zs = Z * sigma_p;                                         /* float * float */
     double t_hat_mas = t_hat / (1.0 + (double)zs);
-    double K_mas = ((1.0 + gamma) * (double)card_b - t_hat_mas) / t_hat_mas;
+    /* :41  ((1.0+gamma)*card_B - t_hat_mas) / t_hat_mas -- the product's only use is the subtraction, so the
+     * reference's FMA build fuses it (see the note above orc_ertl_ml_estimate_ex) */
+    double K_mas = muladd(1.0 + gamma, (double)card_b, -t_hat_mas, g_orc_fma) / t_hat_mas;
     return K_mas;
 }
 

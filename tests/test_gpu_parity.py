@@ -95,6 +95,59 @@ def test_influenza_filelist_text(a, h):
         os.chdir(cwd)
 
 
+@pytest.mark.parametrize("name", ["synth_spread_n600_m64", "synth_flat_n300_m512", "synth_flat_n200_m128"])
+@pytest.mark.parametrize("fp_mode", [FP_FMA, FP_STRICT])
+def test_aux_hll_criteria_vs_oracle_and_golden(oracle, name, fp_mode):
+    """hll_a (selection.cpp:122-173), hll_an (:175-227) and the two-stage hll_a + smh_a of BASELINE config 5"""
+    cfg = make_golden.GOLDEN_SYNTH[name]
+    hll, aux, cards, perm, aux_hll = sorted_set(cfg, oracle, fp_mode)
+    names = [f"g{g:06d}" for g in perm]
+    flavour = "fma" if fp_mode == FP_FMA else "nofma"
+    oracle.set_fma(fp_mode)
+    try:
+        with Selector(0, fp_mode) as sel:
+            sel.upload(hll, aux, cards)
+            sel.upload_aux_hll(aux_hll, 8)
+            for tau in (cfg.tau, 0.5):
+                r, b = pkg.banding(cfg.m, tau)
+                for crit in (pkg.CRIT_HLL_A, pkg.CRIT_HLL_AN, pkg.CRIT_HLL_A_SMH_A):
+                    sel.set_criterion(crit)
+                    for mode, use_cb in ((MODE_CB_SMH, True), (MODE_SMH, False)):
+                        want, st = oracle.select(hll, aux, cards, tau, r, b, use_cb=use_cb, criterion=crit, aux_hll=aux_hll, p_aux=8)
+                        for algo in ((ALGO_STREAM, ALGO_AUTO) if crit == pkg.CRIT_HLL_A_SMH_A else (ALGO_AUTO,)):
+                            got = sel.run(tau, mode, r, b, algo=algo)
+                            assert_same_pairs(got, want)
+                            s = sel.stats()
+                            assert s["evaluated"] == st["evaluated"] and s["survivors"] == st["survivors"], (crit, mode, s, st)
+                        if crit == pkg.CRIT_HLL_A and use_cb and tau == cfg.tau:
+                            assert pkg.format_lines(names, got) == (EXP / f"{name}_hll_a_h{cfg.tau}.{flavour}.txt").read_text()
+            sel.set_criterion(pkg.CRIT_SMH_A)
+            want, _ = oracle.select(hll, aux, cards, cfg.tau, *pkg.banding(cfg.m, cfg.tau))
+            assert_same_pairs(sel.run(cfg.tau), want)
+        # a context without auxiliary sketches refuses the criterion loudly
+        with Selector(0, fp_mode) as sel:
+            sel.upload(hll, aux, cards)
+            sel.set_criterion(pkg.CRIT_HLL_A)
+            with pytest.raises(pkg.SelhipError):
+                sel.run(cfg.tau)
+    finally:
+        oracle.set_fma(1)
+
+
+@pytest.mark.parametrize("crit", ["hll_a", "hll_an"])
+@pytest.mark.parametrize("h", [0.9, 0.5, 0.01])
+def test_influenza_hll_criteria_text(crit, h):
+    import os
+    cwd = os.getcwd()
+    os.chdir(GOLDEN)
+    try:
+        for fp_mode, flavour in ((FP_FMA, "fma"), (FP_STRICT, "nofma")):
+            got = pkg.select_from_filelist("influenza_filelist.txt", h, 256, fp_mode=fp_mode, criterion=crit)
+            assert got == (EXP / f"influenza_{crit}_a256_h{h}.{flavour}.txt").read_text()
+    finally:
+        os.chdir(cwd)
+
+
 def test_row_shards_union_equals_whole(oracle):
     cfg = make_golden.GOLDEN_SYNTH["synth_flat_n1000_m256"]
     hll, aux, cards, _, _ = sorted_set(cfg, oracle)
