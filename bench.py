@@ -80,10 +80,14 @@ def main():
     n_rows, n_bands = pkg.banding(cfg.m, cfg.tau)
 
     # ---- inputs: generated in HBM, sorted into rank order (identical replica on every rank) --------------
-    hll_t, aux_t, cards_t, _, _ = pkg.synth_device(cfg, device=local_rank)
+    hll_t, aux_t, cards_t, _, aux_hll_t = pkg.synth_device(cfg, device=local_rank)
     cards = cards_t.cpu().numpy()
     sel = pkg.Selector(local_rank)
     sel.attach(hll_t, aux_t, cards_t)
+    two_stage = cfg.p_aux > 0                      # BASELINE configs[4]: hll_a prefilter + smh_a
+    if two_stage:
+        sel.attach_aux_hll(aux_hll_t, cfg.p_aux)
+        sel.set_criterion(pkg.CRIT_HLL_A_SMH_A)
 
     # ---- shard the pair space by query rows: equal pair counts per rank ------------------------------------
     bounds = np.zeros(world + 1, dtype=np.int64)
@@ -163,16 +167,23 @@ def main():
 
     out = None
     if rank == 0:
-        pairs_per_launch_rank0 = st["evaluated"]
-        alg_bytes = pairs_per_launch_rank0 * 8 * cfg.m           # 8*m bytes per pair-comparison
-        achieved = alg_bytes / (stage1_ms * 1e-3) / 1e9 if stage1_ms > 0 else None
+        used_sig = sel.kernel_ms("join") > 0
+        pairs_rank0 = st["evaluated"]
+        alg_bytes = pairs_rank0 * 8 * cfg.m                     # 8*m bytes per pair-comparison
+        dom_ms = sel.kernel_ms("join") if used_sig else stage1_ms
+        dom_name = f"sig_join_kernel<{n_bands}>" if used_sig else "smh_stream_kernel"
+        achieved = alg_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else None
         traffic = None
         tfile = ROOT / "profiles" / "stage1_traffic.json"
         if tfile.exists():
             try:
-                traffic = json.loads(tfile.read_text()).get(f"{args.workload}:{args.algo}")
+                traffic = json.loads(tfile.read_text()).get(f"{args.workload}:{'sig' if used_sig else 'stream'}")
             except Exception:
                 traffic = None
+        hist_ms = sel.kernel_ms("hist")
+        surv0 = st["survivors"]
+        kernels = {k: sel.kernel_ms(k) for k in ("prep", "sigbuild", "join", "verify", "stage1", "aux", "hist", "select", "total")
+                   if sel.kernel_ms(k) > 0}
         out = {
             "metric": "sketch pair-comparisons/sec (N genomes x m buckets)",
             "value": value, "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -180,18 +191,31 @@ def main():
             "vs_baseline": None, "dtype": "u64", "data": "synthetic",
             "config": {"workload": f"{cfg.name}; mode {args.mode}; bands {n_bands} x {n_rows} rows; "
                                    f"pair space sharded by query rows over {world} GPU(s), selected pairs all_gathered",
-                       "n_genomes": n_genomes, "m": cfg.m, "tau": cfg.tau, "algo": args.algo,
+                       "n_genomes": n_genomes, "m": cfg.m, "tau": cfg.tau, "algo": "sig" if used_sig else "stream",
+                       "criterion": "hll_a+smh_a" if two_stage else "smh_a",
                        "pairs_per_step": pairs_per_step, "selected_pairs": int(totals[2].item()),
                        "stage1_survivors": int(totals[1].item())},
             "bucket_pair_comparisons_per_s": value * cfg.m,
-            "roofline": {"bound": "hbm", "kernel": "smh_stream_kernel (stage 1)", "achieved": achieved, "peak": HBM_PEAK_GBS,
+            "roofline": {"bound": "hbm", "kernel": dom_name + " (stage 1, all-pairs)", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
-                         "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": stage1_ms,
-                         "note": "algorithmic bytes = 8*m per pair (one candidate sketch per pair, query in LDS); "
-                                 "each streamed candidate is compared against a tile of query sketches held on chip, "
-                                 "so the algorithmic rate may exceed the HBM peak; `traffic` = measured HBM bytes/launch"},
-            "kernel_ms": {"stage1": stage1_ms, **others_ms},
+                         "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": dom_ms,
+                         "note": "algorithmic bytes = 8*m per pair-comparison (SURVEY.md 8d: one candidate sketch streamed per "
+                                 "pair, query on chip). Both stage-1 kernels reuse every byte they load across a tile of "
+                                 "queries, so the algorithmic rate exceeds the HBM peak; `traffic` = measured HBM bytes/launch "
+                                 "(rocprofv3 FETCH_SIZE/WRITE_SIZE, profiles/). The signature join is bound by VALU issue "
+                                 "(1.5 VALU per band and 64 pairs), see `valu`."},
+            "stage2_roofline": {"bound": "hbm", "kernel": "hll_union_hist_kernel", "achieved": (surv0 * 32768 / (hist_ms * 1e-3) / 1e9) if hist_ms > 0 else None,
+                                "peak": HBM_PEAK_GBS, "unit": "GB/s", "avg_launch_ms": hist_ms, "algorithmic_bytes_per_launch": surv0 * 32768,
+                                "note": "2 x 16 KiB of HLL registers per surviving pair"},
+            "kernel_ms": kernels,
         }
+        if used_sig and dom_ms > 0:
+            groups = (n_genomes + 63) // 64
+            wave_queries = pairs_rank0 / 64.0                    # one query against one 64-candidate group
+            valu = wave_queries * n_bands * 1.5
+            out["roofline"]["valu"] = {"achieved_wave_instr_per_s": valu / (dom_ms * 1e-3), "peak_wave_instr_per_s": 256 * 4 * 2.4e9 / 4,
+                                       "frac": valu / (dom_ms * 1e-3) / (256 * 4 * 2.4e9 / 4),
+                                       "note": "peak = 1024 SIMDs x 2.4 GHz / 4 cycles per wave64 VALU instruction"}
 
     # ---- CPU baseline: the oracle (OpenMP port of selection.cpp:270-291 / time_smh.cpp:229-257) on a bounded sample
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -201,24 +225,27 @@ def main():
         cores = os.cpu_count() or 1
         use_cb = mode == pkg.MODE_CB_SMH
 
-        def cpu_run(ns):
+        def cpu_run(ns, reps=1):
             h = hll_t[:ns].cpu().numpy()
             a = aux_t[:ns].cpu().numpy().view(np.uint64)
+            ah = aux_hll_t[:ns].cpu().numpy() if two_stage else None
             c = cards[:ns]
             t = time.perf_counter()
-            pairs, s = orc.select(h, a, c, cfg.tau, n_rows, n_bands, use_cb=use_cb, threads=cores)
-            return time.perf_counter() - t, s["evaluated"], len(pairs)
+            for _ in range(reps):
+                pairs, s = orc.select(h, a, c, cfg.tau, n_rows, n_bands, use_cb=use_cb, threads=cores,
+                                      criterion=3 if two_stage else 0, aux_hll=ah, p_aux=cfg.p_aux or 8)
+            return time.perf_counter() - t, s["evaluated"] * reps, len(pairs)
 
         ns = min(n_genomes, 2000)
         t_probe, ev, _ = cpu_run(ns)
         rate = ev / max(t_probe, 1e-9)
-        ns2 = int(min(n_genomes, max(ns, math.sqrt(2 * rate * args.cpu_seconds))))
-        if ns2 > ns * 1.2:
-            t_probe, ev, nsel = cpu_run(ns2)
-            ns = ns2
+        ns = int(min(n_genomes, max(ns, math.sqrt(2 * rate * args.cpu_seconds))))
+        t1, ev1, _ = cpu_run(ns)                                 # one pass at the chosen size, then repeat to fill the budget
+        reps = int(max(1, min(200, args.cpu_seconds / max(t1, 1e-3))))
+        t_probe, ev, nsel = cpu_run(ns, reps)
         out["cpu_baseline"] = {"value": ev / t_probe, "unit": "pairs/s", "cores": cores, "kind": "port",
-                               "sample": f"first {ns} genomes (rank order) of the same set: {ev} pairs in {t_probe:.2f} s, "
-                                         f"oracle/liboracle.so orc_select, OpenMP schedule(dynamic) over rows"}
+                               "sample": f"first {ns} genomes (rank order) of the same set, {reps} pass(es): {ev} pairs in {t_probe:.2f} s; "
+                                         f"oracle/liboracle.so orc_select = OpenMP port of src/selection.cpp:270-291, schedule(dynamic) over rows"}
     if rank == 0:
         print(json.dumps(out), flush=True)
     sel.close()
