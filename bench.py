@@ -41,6 +41,8 @@ def parse():
     ap.add_argument("--mode", choices=["smh_a", "CB+smh_a"], default="smh_a")
     ap.add_argument("--algo", choices=["auto", "stream", "sig"], default="auto")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
+                    help="gloo = rehearsal of the multi-rank logic on a box with fewer GPUs than ranks (records staged through the host)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the baseline sample")
     return ap.parse_args()
 
@@ -64,11 +66,16 @@ def main():
         args.gpus = world
     if not torch.cuda.is_available():
         sys.exit("bench.py needs an MI355X: the product path has no CPU fallback")
+    local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+    cdev = dev if args.backend == "nccl" else torch.device("cpu")       # where the collectives run
 
     base = pkg.SYNTH_CONFIGS[args.workload]
     n_genomes = args.genomes or base.n_genomes
@@ -111,23 +118,35 @@ def main():
     assert rc == 0
     row_lo, row_hi = int(bounds[rank]), int(bounds[rank + 1])
 
-    # gather buffers (fixed capacity so that the timed loop allocates nothing)
-    cap_records = max(1 << 16, 8 * n_genomes)
-    send = torch.zeros((cap_records, 2), dtype=torch.int64, device=dev)          # 16 B records
-    counts_t = torch.zeros(world, dtype=torch.int64, device=dev)
-    my_count = torch.zeros(1, dtype=torch.int64, device=dev)
-    recv = torch.zeros((world, cap_records, 2), dtype=torch.int64, device=dev) if world > 1 else None
+    # gather: ONE all_gather per step of a fixed-capacity record buffer whose record 0 carries the count.
+    # The capacity is sized from the first (untimed) step: 1.25 x the largest per-rank count, so the timed loop
+    # allocates nothing and exchanges ~16 B per selected pair, not a worst-case buffer.
+    state = {"cap": 0, "send": None, "recv": None, "host": None}
+
+    def size_gather(local_count):
+        mx = torch.tensor([local_count], dtype=torch.int64, device=cdev)
+        if world > 1:
+            dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+        cap = (int(mx.item()) * 5 // 4 + 4096) // 4096 * 4096
+        state["cap"] = cap
+        state["send"] = torch.zeros((cap + 1, 2), dtype=torch.int64, device=dev)              # 16 B records
+        state["recv"] = torch.zeros((world, cap + 1, 2), dtype=torch.int64, device=cdev) if world > 1 else None
+        state["host"] = torch.zeros((cap + 1, 2), dtype=torch.int64).pin_memory() if args.backend == "gloo" else None
 
     def step():
         sel.run(cfg.tau, mode, n_rows, n_bands, rows=(row_lo, row_hi), algo=algo, fetch=False)
         cnt = sel.result_count()
-        if cnt > cap_records:
-            raise RuntimeError("gather buffer too small")
-        sel.copy_results_to(send)
+        if state["send"] is None or cnt > state["cap"]:
+            size_gather(cnt)
+        send = state["send"]
+        send[0, 0] = cnt
+        sel.copy_results_to(send[1:])
         if world > 1:
-            my_count.fill_(cnt)
-            dist.all_gather_into_tensor(counts_t, my_count)                       # RCCL
-            dist.all_gather_into_tensor(recv.view(-1), send.view(-1))             # RCCL over xGMI
+            if args.backend == "nccl":
+                dist.all_gather_into_tensor(state["recv"].view(-1), send.view(-1))            # RCCL over xGMI
+            else:
+                state["host"].copy_(send)
+                dist.all_gather_into_tensor(state["recv"].view(-1), state["host"].view(-1))
         return cnt
 
     def sync_all():
@@ -149,9 +168,9 @@ def main():
     stage1_ms = sel.kernel_ms("stage1")
     others_ms = {k: sel.kernel_ms(k) for k in ("prep", "hist", "select", "total")}
 
-    t_max = torch.tensor([dt], dtype=torch.float64, device=dev)
-    totals = torch.tensor([st["evaluated"], st["survivors"], st["selected"]], dtype=torch.int64, device=dev)
-    s1 = torch.tensor([stage1_ms], dtype=torch.float64, device=dev)
+    t_max = torch.tensor([dt], dtype=torch.float64, device=cdev)
+    totals = torch.tensor([st["evaluated"], st["survivors"], st["selected"]], dtype=torch.int64, device=cdev)
+    s1 = torch.tensor([stage1_ms], dtype=torch.float64, device=cdev)
     if world > 1:
         dist.all_reduce(t_max, op=dist.ReduceOp.MAX)
         dist.all_reduce(totals, op=dist.ReduceOp.SUM)
@@ -160,10 +179,17 @@ def main():
     pairs_per_step = int(totals[0].item())
     value = pairs_per_step * args.steps / dt
 
-    # ---- result check outside the timed region: gathered list == union of shards, sorted unique ------------
+    # ---- result check outside the timed region: the gathered list holds every rank's records -------------------
     if world > 1:
-        cts = counts_t.cpu().numpy()
+        rec = state["recv"].cpu().numpy()
+        cts = rec[:, 0, 0]
         assert int(cts.sum()) == int(totals[2].item()), (cts, totals)
+        allp = np.concatenate([rec[r, 1:1 + int(cts[r])].reshape(-1).view(PAIR_DTYPE) for r in range(world)])
+        key = allp["i"].astype(np.int64) * n_genomes + allp["k"]
+        assert len(np.unique(key)) == len(key), "duplicate pairs across shards"
+        for r in range(world):                        # every record sits in the row range of the rank that sent it
+            ii = rec[r, 1:1 + int(cts[r])].reshape(-1).view(PAIR_DTYPE)["i"]
+            assert ((ii >= bounds[r]) & (ii < bounds[r + 1])).all()
 
     out = None
     if rank == 0:
