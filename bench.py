@@ -41,6 +41,7 @@ def parse():
     ap.add_argument("--mode", choices=["smh_a", "CB+smh_a"], default="smh_a")
     ap.add_argument("--algo", choices=["auto", "stream", "sig"], default="auto")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--pcie", action="store_true", help="also time a PCIe-inclusive pass (host buffers -> upload -> run)")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
                     help="gloo = rehearsal of the multi-rank logic on a box with fewer GPUs than ranks (records staged through the host)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the baseline sample")
@@ -272,6 +273,53 @@ def main():
         out["cpu_baseline"] = {"value": ev / t_probe, "unit": "pairs/s", "cores": cores, "kind": "port",
                                "sample": f"first {ns} genomes (rank order) of the same set, {reps} pass(es): {ev} pairs in {t_probe:.2f} s; "
                                          f"oracle/liboracle.so orc_select = OpenMP port of src/selection.cpp:270-291, schedule(dynamic) over rows"}
+        # ---- the REFERENCE's own CPU program (oracle/_ref/selection, built from the unmodified sources in the
+        # authoring container and shipped prebuilt) on sketch FILES written from the same set: two sizes, so that
+        # file loading cancels in the difference (the program does not time its loop separately).
+        ref_bin = ROOT / "oracle" / "_ref" / "selection"
+        if ref_bin.exists() and not use_cb is None and not two_stage:
+            import subprocess
+            import tempfile
+            try:
+                host = pkg.host_lib()
+                n2 = min(n_genomes, 6000)
+                n1 = n2 // 2
+                with tempfile.TemporaryDirectory() as td:
+                    h = hll_t[:n2].cpu().numpy()
+                    a = aux_t[:n2].cpu().numpy().view(np.uint64)
+                    for g in range(n2):
+                        base_ = f"{td}/g{g:06d}".encode()
+                        host.selhost_write_hll(base_ + b".hll", h[g].ctypes.data, 14)
+                        host.selhost_write_smh(base_ + f".smh{cfg.m}".encode(), a[g].ctypes.data, cfg.m)
+                    times = []
+                    for nn in (n1, n2):
+                        Path(td, f"list{nn}.txt").write_text("".join(f"g{g:06d}\n" for g in range(nn)))
+                        t = time.perf_counter()
+                        subprocess.run([str(ref_bin), "-l", f"list{nn}.txt", "-t", str(min(cores, 64)), "-a", str(cfg.m * 8),
+                                        "-h", str(cfg.tau), "-c", "smh_a"], cwd=td, check=True, capture_output=True)
+                        times.append(time.perf_counter() - t)
+                dp = n2 * (n2 - 1) // 2 - n1 * (n1 - 1) // 2
+                dtm = times[1] - times[0]
+                if dtm <= 0:
+                    out["cpu_reference"] = {"error": f"non-positive time difference: {times}"}
+                else:
+                    out["cpu_reference"] = {"value": dp / dtm, "unit": "pairs/s", "cores": min(cores, 64), "kind": "reference",
+                                            "sample": f"oracle/_ref/selection (the reference's src/selection.cpp, g++ -O3 -march=x86-64-v3 -fopenmp) "
+                                                      f"-c smh_a on the first {n1} and {n2} genomes written as .hll/.smh{cfg.m} files: "
+                                                      f"{times[0]:.2f} s and {times[1]:.2f} s wall, difference = {dp} pairs (CB+smh_a mode, the program's only mode)"}
+            except Exception as e:                     # the reference binary is optional equipment
+                out["cpu_reference"] = {"error": str(e)[:200]}
+    if rank == 0 and world == 1 and args.pcie:
+        # PCIe-inclusive variant (never `value`): host buffers handed to selhip_ctx_upload, then one pass
+        h = hll_t.cpu().numpy(); a = aux_t.cpu().numpy().view(np.uint64)
+        with pkg.Selector(local_rank) as s2:
+            t = time.perf_counter()
+            s2.upload(h, a, cards)
+            s2.run(cfg.tau, mode, n_rows, n_bands, algo=algo, fetch=False)
+            dt2 = time.perf_counter() - t
+            ev2 = s2.stats()["evaluated"]
+        out["pcie_inclusive"] = {"pairs_per_s": ev2 / dt2, "seconds": dt2, "bytes_uploaded": int(h.nbytes + a.nbytes + cards.nbytes),
+                                 "note": "pageable host buffers -> selhip_ctx_upload -> one pass; not the headline"}
     if rank == 0:
         print(json.dumps(out), flush=True)
     sel.close()
