@@ -94,3 +94,35 @@ class Oracle:
             if cnt <= cap:
                 return out[:cnt], {"evaluated": st[0], "survivors": st[1], "selected": cnt}
             cap = int(cnt)
+
+
+class BuildOracle:
+    """oracle/build_sketch_oracle.c: sequential restatement of src/build_sketch.cpp + SuperMinHash/HLL addh"""
+
+    def __init__(self):
+        self.lib = C.CDLL(str(ROOT / "oracle" / "liboracle.so"))
+        L = self.lib
+        L.orcb_smh_new.restype = C.c_void_p
+        L.orcb_smh_new.argtypes = [C.c_size_t]
+        L.orcb_smh_data.restype = C.c_void_p
+        L.orcb_smh_data.argtypes = [C.c_void_p]
+        L.orcb_smh_size.restype = C.c_uint32
+        L.orcb_smh_size.argtypes = [C.c_void_p]
+        L.orcb_smh_free.argtypes = [C.c_void_p]
+        L.orcb_sketch_file.restype = C.c_longlong
+        L.orcb_sketch_file.argtypes = [C.c_char_p, C.c_uint, C.c_void_p, C.c_void_p, C.c_uint, C.c_void_p]
+
+    def sketch(self, path, m=0, p_aux=0, k=31):
+        """returns (hll14 u8[16384], aux u8[1<<p_aux] or None, smh u64[m'] or None, n_kmers)"""
+        hll = np.zeros(16384, dtype=np.uint8)
+        aux = np.zeros(1 << p_aux, dtype=np.uint8) if p_aux else None
+        smh = self.lib.orcb_smh_new(m) if m else None
+        n = self.lib.orcb_sketch_file(str(path).encode(), k, hll.ctypes.data, aux.ctypes.data if p_aux else None, p_aux, smh)
+        if n < 0:
+            raise RuntimeError(f"cannot read {path}")
+        out = None
+        if smh:
+            cnt = self.lib.orcb_smh_size(smh)
+            out = np.frombuffer((C.c_uint8 * (8 * cnt)).from_address(self.lib.orcb_smh_data(smh)), dtype=np.uint64).copy()
+            self.lib.orcb_smh_free(smh)
+        return hll, aux, out, n
