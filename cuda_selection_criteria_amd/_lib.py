@@ -80,6 +80,7 @@ HIP_SYMBOLS = {
     "selhip_smh_match_counts": (_i, [_vp, _i, _vp, _i64, _vp, _vp]),
     "selhip_synth_generate": (_i, [C.POINTER(Synth), _i64, _i64, _vp, _vp, _vp, _vp]),
     "selhip_permute_rows": (_i, [_vp, _vp, _vp, _i64, _i64, _vp]),
+    "selhip_build_sketches": (_i, [_vp, _vp, _i64, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "selhip_malloc": (_i, [C.POINTER(_vp), _sz]),
     "selhip_free": (_i, [_vp]),
     "selhip_memcpy_h2d": (_i, [_vp, _vp, _sz]),
@@ -94,6 +95,8 @@ HOST_SYMBOLS = {
     "selhost_write_hll": (_i, [_cp, _vp, C.c_uint32]),
     "selhost_read_smh": (_i64, [_cp, _vp, _sz]),
     "selhost_write_smh": (_i, [_cp, _vp, C.c_uint32]),
+    "selhost_fasta_codes": (_i64, [_cp, _vp, _sz]),
+    "selhost_smh_vecsize": (C.c_uint32, [C.c_uint32]),
     "selhost_hll_report": (_d, [_vp, C.c_uint, _i]),
     "selhost_hll_union_size": (_d, [_vp, _vp, C.c_uint, _i]),
     "selhost_ertl_estimate": (_d, [_vp, C.c_uint, _i]),

@@ -114,6 +114,43 @@ int selhost_write_smh(const char* path, const uint64_t* v, uint32_t count) {
     return ok ? SELHOST_OK : fail(SELHOST_E_IO, "Error writing to file '%s'", path);
 }
 
+int64_t selhost_fasta_codes(const char* path, uint8_t* out, size_t cap) {
+    if (!path || (!out && cap)) return fail(SELHOST_E_BADARG, "null argument");
+    gzFile fp = gzopen(path, "rb");
+    if (!fp) return fail(SELHOST_E_IO, "ERROR: Could not open the file %s.", path);      // build_sketch.cpp:44-48
+    int64_t n = 0;
+    bool in_header = false, at_line_start = true;
+    std::vector<char> buf(1 << 16);
+    int got;
+    auto emit = [&](uint8_t c) { if ((size_t)n < cap) out[n] = c; ++n; };
+    while ((got = gzread(fp, buf.data(), (unsigned)buf.size())) > 0) {
+        for (int t = 0; t < got; ++t) {
+            const char c = buf[(size_t)t];
+            if (c == '\n') { in_header = false; at_line_start = true; continue; }
+            if (at_line_start && c == '>') { in_header = true; at_line_start = false; emit(4); continue; }   // new record
+            at_line_start = false;
+            if (in_header || c == '\r' || c == ' ' || c == '\t') continue;
+            switch (c) {                                                                 // build_sketch.cpp:68-84
+                case 'A': case 'a': emit(0); break;
+                case 'C': case 'c': emit(1); break;
+                case 'G': case 'g': emit(2); break;
+                case 'T': case 't': emit(3); break;
+                default: emit(4); break;
+            }
+        }
+    }
+    gzclose(fp);
+    return n;
+}
+
+uint32_t selhost_smh_vecsize(uint32_t arg) {
+    if (arg <= 1) return 1;
+    uint32_t lg = 0;
+    while ((1ull << (lg + 1)) <= arg) ++lg;
+    lg += (arg & (arg - 1)) != 0;
+    return 1u << lg;
+}
+
 // ---- estimator ------------------------------------------------------------------------------------
 double selhost_ertl_estimate(const uint32_t counts[64], unsigned p, int fp_mode) { return estimate(counts, p, fp_mode); }
 double selhost_log1p(double x) { return selhip::log1p_fdlibm(x); }

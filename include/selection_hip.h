@@ -198,6 +198,17 @@ int selhip_permute_rows(const void* d_src, void* d_dst, const int32_t* d_perm, i
                         int64_t row_bytes, void* hip_stream);
 
 /* ---------------------------------------------------------------------------------------------------
+ * 4b. Sketch construction (the `build_sketch` step, src/build_sketch.cpp:26-151): canonical k-mers of every
+ *     genome -> HLL p=14 registers, optional auxiliary HLL (p_aux) and optional SuperMinHash h_[m], byte-identical
+ *     to the files the reference writes.  d_codes: one byte per base (0..3 = A,C,G,T; 4 = window reset: non-ACGT
+ *     character or record boundary), genomes concatenated; d_offsets[n_genomes+1] (int64) delimit them
+ *     (selhost_fasta_codes produces the codes).  d_smh / d_aux_hll may be NULL.  m must already be rounded up to a
+ *     power of two (policy.h:12-19), m <= 2048.  One workgroup per genome.
+ * --------------------------------------------------------------------------------------------------- */
+int selhip_build_sketches(const uint8_t* d_codes, const int64_t* d_offsets, int64_t n_genomes, int k, int m, int p_aux,
+                          uint8_t* d_hll, uint64_t* d_smh, uint8_t* d_aux_hll, void* hip_stream);
+
+/* ---------------------------------------------------------------------------------------------------
  * 5. Plain device-memory helpers so that a host program needs no HIP headers (the reference driver
  *    calls cudaMalloc/cudaMemcpy/cudaFree directly, selection_cuda.cpp:160-182).
  * --------------------------------------------------------------------------------------------------- */

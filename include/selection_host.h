@@ -42,6 +42,14 @@ int selhost_write_hll(const char* path, const uint8_t* core, uint32_t p);   /* h
 int64_t selhost_read_smh(const char* path, uint64_t* out, size_t cap);      /* returns count or <0 */
 int selhost_write_smh(const char* path, const uint64_t* v, uint32_t count);
 
+/* FASTA(.gz) -> one byte per base for selhip_build_sketches: 0..3 = A,C,G,T in either case, 4 = k-mer window reset
+ * (any other sequence character; one is also emitted at every record start).  Header lines ('>'...) and white space
+ * are skipped.  Mirrors what src/build_sketch.cpp:49-84 feeds its k-mer loop through SeqAn's readRecord.
+ * Returns the number of codes (only the first `cap` are stored: call again with a larger buffer) or <0. */
+int64_t selhost_fasta_codes(const char* path, uint8_t* out, size_t cap);
+/* SizePow2Policy::arg2vecsize (sketch/policy.h:12-19): the bucket count a SuperMinHash<>(arg) really has */
+uint32_t selhost_smh_vecsize(uint32_t arg);
+
 /* ---- estimator on the host (same header as the device code: csrc/ertl_mle.hpp) ---------------- */
 /* fp_mode: 1 = fused like the reference built by its Makefile on an FMA host, 0 = strict */
 double selhost_hll_report(const uint8_t* core, unsigned p, int fp_mode);
