@@ -896,20 +896,53 @@ __device__ __forceinline__ bool kmer_at(const uint8_t* __restrict__ codes, long 
     return ok;
 }
 
+// byte-wide HLL registers packed four to an LDS word: max via read-check + CAS (updates become rare once the
+// registers have warmed up, so the CAS loop almost never runs)
+__device__ __forceinline__ void lds_byte_max(uint32_t* words, uint32_t idx, uint32_t rank) {
+    uint32_t* w = words + (idx >> 2);
+    const int sh = (idx & 3) * 8;
+    uint32_t cur = *(volatile uint32_t*)w;
+    while (((cur >> sh) & 0xFFu) < rank) {
+        const uint32_t want = (cur & ~(0xFFu << sh)) | (rank << sh);
+        const uint32_t prev = atomicCAS(w, cur, want);
+        if (prev == cur) break;
+        cur = prev;
+    }
+}
+
 constexpr int kSketchJmaxParallel = 15;
+constexpr int kSketchSeg = 64;          // consecutive k-mer end positions rolled by one thread
+
+// visits every valid k-mer of the genome once: thread t owns segments t, t+256, ... of kSketchSeg end positions and
+// rolls the 2-bit window through them (30 warm-up bases per segment)
+template <typename F>
+__device__ __forceinline__ void for_each_kmer(const uint8_t* __restrict__ codes, long long L, int k, F&& f) {
+    const u64 kmask = k == 32 ? ~0ull : ((1ull << (2 * k)) - 1);
+    for (long long seg = (long long)(k - 1) + (long long)threadIdx.x * kSketchSeg; seg < L; seg += (long long)kBlock * kSketchSeg) {
+        const long long end = min(seg + kSketchSeg, L);
+        u64 kmer = 0;
+        int bases = 0;                                       // valid bases in the window, capped at k
+        for (long long i = seg - (k - 1); i < end; ++i) {
+            const uint32_t c = codes[i];
+            if (c < 4) { kmer = ((kmer << 2) | c) & kmask; bases = min(bases + 1, k); }
+            else       { kmer = 0; bases = 0; }                                       // build_sketch.cpp:83
+            if (i >= seg && bases == k) f(kmer);
+        }
+    }
+}
 
 __global__ __launch_bounds__(kBlock)
 void sketch_build_kernel(const uint8_t* __restrict__ codes_all, const long long* __restrict__ offsets, int k,
                          int m, int p_aux, uint8_t* __restrict__ hll_out, u64* __restrict__ smh_out,
                          uint8_t* __restrict__ aux_out) {
     extern __shared__ unsigned char smem_raw[];
-    // layout: u64 h[m] | u32 regs[16384] | u32 aregs[1<<p_aux] | u32 p[m] | u32 q[m] | i32 b[m] | i32 ctl[4]
+    // layout: u64 h[m] | u32 regs[16384/4] (byte registers) | u32 aregs[(1<<p_aux)/4] | u32 p[m] | u32 q[m] | i32 b[m] | i32 ctl[4]
     const int n_aux = (aux_out && p_aux > 0) ? (1 << p_aux) : 0;
     const int ms = smh_out ? m : 0;
     u64* h = reinterpret_cast<u64*>(smem_raw);
     uint32_t* regs = reinterpret_cast<uint32_t*>(smem_raw + (size_t)ms * 8);
-    uint32_t* aregs = regs + 16384;
-    uint32_t* pp = aregs + n_aux;
+    uint32_t* aregs = regs + 16384 / 4;
+    uint32_t* pp = aregs + (n_aux + 3) / 4;
     uint32_t* qq = pp + ms;
     int* bb = reinterpret_cast<int*>(qq + ms);
     int* ctl = bb + ms;
@@ -920,27 +953,27 @@ void sketch_build_kernel(const uint8_t* __restrict__ codes_all, const long long*
     const uint32_t mask = (uint32_t)(m - 1);
 
     for (int t = threadIdx.x; t < ms; t += kBlock) h[t] = ~0ull;
-    for (int t = threadIdx.x; t < 16384; t += kBlock) regs[t] = 0;
-    for (int t = threadIdx.x; t < n_aux; t += kBlock) aregs[t] = 0;
+    for (int t = threadIdx.x; t < 16384 / 4; t += kBlock) regs[t] = 0;
+    for (int t = threadIdx.x; t < (n_aux + 3) / 4; t += kBlock) aregs[t] = 0;
     if (threadIdx.x == 0) ctl[0] = 0;
     __syncthreads();
 
     // pass 0: HLL registers and the step-0 offer of every k-mer
-    for (long long i = (k - 1) + threadIdx.x; i < L; i += kBlock) {
-        u64 kmer;
-        if (!kmer_at(codes, i, k, &kmer)) continue;
+    for_each_kmer(codes, L, k, [&](u64 kmer) {
         const u64 canon = canonical_kmer(kmer, (unsigned)k);
         const u64 hv = wang_hash(canon);                                              // hll.h:901-904 addh
         uint32_t idx, rank;
         hll_slot(hv, 14, &idx, &rank);
-        atomicMax(&regs[idx], rank);
-        if (n_aux) { hll_slot(hv, p_aux, &idx, &rank); atomicMax(&aregs[idx], rank); }
+        lds_byte_max(regs, idx, rank);
+        if (n_aux) { hll_slot(hv, p_aux, &idx, &rank); lds_byte_max(aregs, idx, rank); }
         if (ms) {
             u64 st = canon ? canon : 1337ull;                                         // WyRand(seed ? seed : 1337)
             const u64 v = wyhash64_next(st);
-            atomicMin(&h[(uint32_t)v & mask], (u64)(v >> 32));                        // j = 0: bucket k_0, value (0<<32)|r_0
+            const u64 offer = v >> 32;                                                // j = 0: value (0<<32)|r_0
+            u64* slot = &h[(uint32_t)v & mask];                                       //        bucket k_0
+            if (offer < *(volatile u64*)slot) atomicMin(slot, offer);
         }
-    }
+    });
     __syncthreads();
 
     if (ms) {
@@ -994,9 +1027,7 @@ void sketch_build_kernel(const uint8_t* __restrict__ codes_all, const long long*
             }
             J = a;
             // every k-mer re-runs its chain up to step J; only steps >= 1 can be new (atomic min is idempotent)
-            for (long long i = (k - 1) + threadIdx.x; i < L; i += kBlock) {
-                u64 kmer;
-                if (!kmer_at(codes, i, k, &kmer)) continue;
+            for_each_kmer(codes, L, k, [&](u64 kmer) {
                 const u64 canon = canonical_kmer(kmer, (unsigned)k);
                 u64 st = canon ? canon : 1337ull;
                 uint32_t pos[2 * (kSketchJmaxParallel + 1)], val[2 * (kSketchJmaxParallel + 1)];
@@ -1018,15 +1049,14 @@ void sketch_build_kernel(const uint8_t* __restrict__ codes_all, const long long*
                     const uint32_t bucket = (kk == (uint32_t)j) ? pj : pk;            // p[j] after the swap
                     atomicMin(&h[bucket], ((u64)j << 32) | (v >> 32));
                 }
-            }
+            });
             __syncthreads();
         }
     }
     __syncthreads();
     uint32_t* out32 = reinterpret_cast<uint32_t*>(hll_out + g * 16384);
-    for (int t = threadIdx.x; t < 16384 / 4; t += kBlock)
-        out32[t] = regs[4 * t] | (regs[4 * t + 1] << 8) | (regs[4 * t + 2] << 16) | (regs[4 * t + 3] << 24);
-    for (int t = threadIdx.x; t < n_aux; t += kBlock) aux_out[g * n_aux + t] = (uint8_t)aregs[t];
+    for (int t = threadIdx.x; t < 16384 / 4; t += kBlock) out32[t] = regs[t];
+    for (int t = threadIdx.x; t < n_aux; t += kBlock) aux_out[g * n_aux + t] = (uint8_t)(aregs[t >> 2] >> ((t & 3) * 8));
     for (int t = threadIdx.x; t < ms; t += kBlock) smh_out[g * (long long)m + t] = h[t];
 }
 
@@ -1975,7 +2005,7 @@ int selhip_build_sketches(const uint8_t* d_codes, const int64_t* d_offsets, int6
     if (d_aux_hll && (p_aux < 4 || p_aux > 12)) { set_err(nullptr, "p_aux out of range [4,12]"); return SELHIP_E_BADARG; }
     if (n_genomes == 0) return SELHIP_OK;
     const size_t ms = d_smh ? (size_t)m : 0;
-    const size_t smem = ms * 8 + 16384 * 4 + (d_aux_hll ? ((size_t)4 << p_aux) : 0) + ms * 12 + 16;
+    const size_t smem = ms * 8 + 16384 + (d_aux_hll ? ((((size_t)1 << p_aux) + 3) / 4 * 4) : 0) + ms * 12 + 16;
     static bool attr_set = false;
     if (!attr_set) {
         HIPCHK(nullptr, hipFuncSetAttribute((const void*)sketch_build_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
