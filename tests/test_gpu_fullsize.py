@@ -1,0 +1,104 @@
+"""BASELINE.json sizes on the GPU: bit-exact against the oracle where the oracle finishes in seconds (configs 2, 3),
+and size-independent properties beyond that (two independent GPU algorithms agree, shards tile the pair space,
+planted near-duplicates are found, runs are idempotent, two-stage = intersection of its stages on sampled rows)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+import cuda_selection_criteria_amd as pkg  # noqa: E402
+from cuda_selection_criteria_amd import ALGO_SIG, ALGO_STREAM, MODE_CB_SMH, MODE_SMH, Selector  # noqa: E402
+
+
+def fetch_np(hll_t, aux_t, cards_t):
+    return hll_t.cpu().numpy(), aux_t.cpu().numpy().view(np.uint64), cards_t.cpu().numpy()
+
+
+def same(got, want):
+    return (len(got) == len(want) and np.array_equal(got["i"], want["i"]) and np.array_equal(got["k"], want["k"])
+            and np.array_equal(got["jaccard"].view(np.uint64), want["jacc"].view(np.uint64)))
+
+
+@pytest.mark.parametrize("key", ["cfg2", "cfg3", "cfg3-spread"])
+def test_baseline_configs_bit_exact_vs_oracle(oracle, key):
+    """configs[1] (1 000 genomes, m=256, tau=0.9) and configs[2] (10 000 genomes, m=512, tau=0.8) at FULL size"""
+    cfg = pkg.SYNTH_CONFIGS[key]
+    hll_t, aux_t, cards_t, _, _ = pkg.synth_device(cfg)
+    hll, aux, cards = fetch_np(hll_t, aux_t, cards_t)
+    assert np.array_equal(cards.view(np.uint64), oracle.cards(hll).view(np.uint64))       # device report() at full size
+    r, b = pkg.banding(cfg.m, cfg.tau)
+    with Selector(0) as sel:
+        sel.attach(hll_t, aux_t, cards_t)
+        for mode, use_cb in ((MODE_SMH, False), (MODE_CB_SMH, True)):
+            want, st = oracle.select(hll, aux, cards, cfg.tau, r, b, use_cb=use_cb, threads=16)
+            for algo in (ALGO_SIG, ALGO_STREAM):
+                got = sel.run(cfg.tau, mode, r, b, algo=algo)
+                assert same(got, want), (key, mode, algo, len(got), len(want))
+                s = sel.stats()
+                assert s["evaluated"] == st["evaluated"] and s["survivors"] == st["survivors"]
+            if key == "cfg3" and not use_cb:
+                assert st["evaluated"] == 49_995_000 and len(want) == 45_000               # 1000 clusters x C(10,2)
+
+
+def test_config4_scale_properties():
+    """50 000 genomes, m=512 (configs[3]; 1.25e9 pairs -- beyond the oracle's reach in a test): properties only"""
+    cfg = pkg.SYNTH_CONFIGS["cfg4"]
+    hll_t, aux_t, cards_t, perm, _ = pkg.synth_device(cfg)
+    r, b = pkg.banding(cfg.m, cfg.tau)
+    n = cfg.n_genomes
+    with Selector(0) as sel:
+        sel.attach(hll_t, aux_t, cards_t)
+        whole = sel.run(cfg.tau, MODE_SMH, r, b)
+        st = sel.stats()
+        assert st["evaluated"] == n * (n - 1) // 2
+        # every in-cluster pair (expected Jaccard >= 0.83) and nothing else: 5000 clusters x 45 pairs
+        cluster = perm // cfg.cluster_size
+        assert (cluster[whole["i"]] == cluster[whole["k"]]).all()
+        assert len(whole) == (n // cfg.cluster_size) * 45
+        assert (whole["i"] < whole["k"]).all() and (whole["jaccard"] >= np.float32(cfg.tau)).all()
+        key = whole["i"].astype(np.int64) * n + whole["k"]
+        assert (np.diff(key) > 0).all()                                                    # sorted by (i,k), unique
+        # idempotent
+        again = sel.run(cfg.tau, MODE_SMH, r, b)
+        assert np.array_equal(again, whole)
+        # 8 equal-pair shards (the multi-GPU decomposition) tile the result
+        from cuda_selection_criteria_amd import distributed as D
+        bounds = D.shard_rows(n, 8)
+        parts = [sel.run(cfg.tau, MODE_SMH, r, b, rows=(int(bounds[j]), int(bounds[j + 1]))) for j in range(8)]
+        assert np.array_equal(np.concatenate(parts), whole)
+        pc = D.pair_counts(n, bounds)
+        assert pc.sum() == n * (n - 1) // 2 and pc.max() < 1.01 * pc.mean()
+        # the literal stream kernel agrees on a band of rows (an independent implementation of stage 1)
+        lo, hi = 20000, 20600
+        a = sel.run(cfg.tau, MODE_SMH, r, b, rows=(lo, hi), algo=ALGO_STREAM)
+        s = sel.run(cfg.tau, MODE_SMH, r, b, rows=(lo, hi), algo=ALGO_SIG)
+        assert np.array_equal(a, s) and len(a) > 0
+
+
+def test_config5_two_stage_properties(oracle):
+    """hll_a (p=8) prefilter + smh_a m=1024 (configs[4]) at 20 000 genomes: two-stage == smh_a result filtered by
+    hll_a, checked pair by pair with the oracle's hll_a on the smh_a survivors"""
+    cfg = pkg.SYNTH_CONFIGS["cfg5"].scaled(20_000)
+    hll_t, aux_t, cards_t, _, aux_hll_t = pkg.synth_device(cfg)
+    r, b = pkg.banding(cfg.m, cfg.tau)
+    with Selector(0) as sel:
+        sel.attach(hll_t, aux_t, cards_t)
+        sel.attach_aux_hll(aux_hll_t, cfg.p_aux)
+        smh = sel.run(cfg.tau, MODE_CB_SMH, r, b)
+        sel.set_criterion(pkg.CRIT_HLL_A_SMH_A)
+        two = sel.run(cfg.tau, MODE_CB_SMH, r, b)
+        st = sel.stats()
+    cards = cards_t.cpu().numpy()
+    ah = aux_hll_t.cpu().numpy()
+    e = cards.astype(np.uint64)
+    keep = []
+    lib = oracle.lib
+    import ctypes as C
+    lib.orc_hll_a_from_union.argtypes = [C.c_double, C.c_size_t, C.c_size_t, C.c_double, C.c_int, C.c_float]
+    tau64 = float(np.float32(cfg.tau))
+    for rec in smh:
+        u = oracle.union_size(ah[rec["i"]], ah[rec["k"]], cfg.p_aux)
+        keep.append(bool(lib.orc_hll_a_from_union(tau64, int(e[rec["i"]]), int(e[rec["k"]]), u, cfg.p_aux, C.c_float(1.96))))
+    want = smh[np.array(keep, dtype=bool)]
+    assert np.array_equal(two, want)
+    assert 0 < len(two) <= len(smh) and st["survivors"] >= len(two)
