@@ -140,8 +140,7 @@ def main():
         if state["send"] is None or cnt > state["cap"]:
             size_gather(cnt)
         send = state["send"]
-        send[0, 0] = cnt
-        sel.copy_results_to(send[1:])
+        sel.copy_results_framed(send)                       # header {count} + records, device-to-device, no host hop
         if world > 1:
             if args.backend == "nccl":
                 dist.all_gather_into_tensor(state["recv"].view(-1), send.view(-1))            # RCCL over xGMI

@@ -72,6 +72,7 @@ HIP_SYMBOLS = {
     "selhip_ctx_fetch": (_i, [_vp, _vp, _i64]),
     "selhip_ctx_result_device": (_i, [_vp, C.POINTER(_vp), C.POINTER(_i64)]),
     "selhip_ctx_copy_results": (_i, [_vp, _vp, _i64]),
+    "selhip_ctx_copy_results_framed": (_i, [_vp, _vp, _i64]),
     "selhip_ctx_kernel_ms": (_d, [_vp, _cp]),
     "selhip_ctx_timing": (_i, [_vp, _i]),
     "selhip_smh_a_pairs": (_i, [_vp, _i, _i, _i, _vp, _i64, _vp, _vp]),

@@ -1,0 +1,66 @@
+// kernel_bounds.cuh -- cb_bounds_kernel: truncated cardinalities, CB cut-off per row, evaluated-pair count.
+// Part of libselhip.so; included by selection_kernels.hip only (one translation unit, anonymous namespace).
+#pragma once
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------
+// cb_bounds_kernel: one thread per genome rank.
+//   ecard[i] = (size_t)cards[i]                                         (selection.cpp:275,280)
+//   hi[i]    = last k such that CB(tau, e_i, e_k) holds, or N-1 without CB  (criteria_sketch.hpp:45-49;
+//              the loop `break`s at the first failing k (selection.cpp:282-283); e is ascending so the
+//              predicate is monotone and the break is exactly "k <= hi(i)")
+//   z0       = first rank with e != 0  (`if(e2 == 0) continue`, selection.cpp:281)
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool cb_pred(double tau, u64 e1, u64 e2) {
+    double gamma = (double)e1 / (double)e2;      // criteria_sketch.hpp:47 (size_t -> double, IEEE divide)
+    return gamma >= tau;
+}
+
+__global__ void cb_bounds_kernel(const double* __restrict__ cards, int n, double tau, int use_cb,
+                                 int row_begin, int row_end, u64* __restrict__ ecard, int* __restrict__ hi,
+                                 PassCounters* __restrict__ pc) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double c = cards[i];
+    u64 e1 = selhip::trunc_card(c);
+    ecard[i] = e1;
+    if (i > 0) {
+        double cp = cards[i - 1];
+        if (c < cp) pc->unsorted = 1;
+        if (e1 != 0 && selhip::trunc_card(cp) == 0) pc->z0p1 = i + 1;
+    } else if (e1 != 0) {
+        pc->z0p1 = 1;
+    }
+    int h = n - 1;
+    if (use_cb) {
+        // largest k in (i, n) with (e_k == 0 || CB(e1, e_k)); predicate is true on a prefix
+        int lo = i, hi_ = n - 1;      // invariant: pred(lo) true (k = i itself counts as true), answer in [lo, hi_]
+        while (lo < hi_) {
+            int mid = lo + (hi_ - lo + 1) / 2;
+            u64 e2 = selhip::trunc_card(cards[mid]);
+            bool ok = (e2 == 0) || cb_pred(tau, e1, e2);
+            if (ok) lo = mid; else hi_ = mid - 1;
+        }
+        h = lo;
+    }
+    hi[i] = h;
+    if (i >= row_begin && i < row_end) {
+        // pairs of this row inside the pair space: k in [max(i+1, z0'), h]; z0 may not be published yet,
+        // so count candidates with e_k != 0 directly from the sorted property: e_k == 0 only for k < z0.
+        // first k > i with e_k != 0: if e1 != 0 it is i+1, else binary search.
+        int first = i + 1;
+        if (e1 == 0) {
+            int lo = i + 1, hi2 = n;          // first index in [i+1, n) with e != 0
+            while (lo < hi2) {
+                int mid = lo + (hi2 - lo) / 2;
+                if (selhip::trunc_card(cards[mid]) != 0) hi2 = mid; else lo = mid + 1;
+            }
+            first = lo;
+        }
+        long long cnt = (long long)h - first + 1;
+        if (cnt > 0) atomicAdd(&pc->n_evaluated, (u64)cnt);
+    }
+}
+
+}  // namespace

@@ -1,0 +1,246 @@
+// kernel_hll.cuh -- stage 2: HLL union histograms, Ertl-MLE + Jaccard selection, auxiliary-HLL criteria (hll_a / hll_an).
+// Part of libselhip.so; included by selection_kernels.hip only (one translation unit, anonymous namespace).
+#pragma once
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------
+// hll_union_hist_kernel: one wave per pair.  LDS holds a lane-private 64-bin histogram per wave
+// ([bin][lane], conflict-free ds_add_u32), reduced with a rotated column walk.
+// counts[j][0..63] = #registers whose max(reg_x, reg_y) equals the bin    (hll.h:1188-1204)
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t max_u8x4(uint32_t a, uint32_t b) {
+    // per-byte unsigned max without carries between bytes
+    uint32_t r = 0;
+#pragma unroll
+    for (int s = 0; s < 32; s += 8) {
+        uint32_t x = (a >> s) & 0xFF, y = (b >> s) & 0xFF;
+        r |= (x > y ? x : y) << s;
+    }
+    return r;
+}
+
+__device__ __forceinline__ void hist_add_word(uint32_t* __restrict__ col, uint32_t w) {
+#pragma unroll
+    for (int s = 0; s < 32; s += 8) {
+        uint32_t v = (w >> s) & 63u;              // register values are <= 64-p+1 < 64
+        __hip_atomic_fetch_add(col + v * kWave, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+}
+
+__global__ __launch_bounds__(kBlock)
+void hll_union_hist_kernel(const uint8_t* __restrict__ hll, int p,
+                           const selhip_int2_t* __restrict__ pairs, const u64* __restrict__ n_pairs_dev,
+                           u64 n_pairs_host, u64 cap, uint32_t* __restrict__ counts,
+                           u64 chunk_off = 0, u64 chunk_len = ~0ull) {
+    __shared__ uint32_t hist[kWavesPerBlock][64 * kWave];     // 64 KiB
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = threadIdx.x / kWave;
+    u64 n_pairs = n_pairs_dev ? *n_pairs_dev : n_pairs_host;
+    if (n_pairs > cap) n_pairs = cap;
+    // optional window [chunk_off, chunk_off + chunk_len) of the list; counts are indexed from the window start
+    n_pairs = n_pairs > chunk_off ? min(n_pairs - chunk_off, chunk_len) : 0;
+    pairs += chunk_off;
+    const long long nreg = 1ll << p;
+    uint32_t* my = hist[wave];
+    uint32_t* col = my + lane;
+
+    for (u64 base = (u64)blockIdx.x * kWavesPerBlock; base < n_pairs; base += (u64)gridDim.x * kWavesPerBlock) {
+        const u64 j = base + wave;
+        const bool active = j < n_pairs;
+        // zero this wave's histogram
+#pragma unroll 8
+        for (int b = 0; b < 64; ++b) col[b * kWave] = 0;
+        __syncthreads();
+        if (active) {
+            const selhip_int2_t pr = pairs[j];
+            const uint8_t* a = hll + (long long)pr.x * nreg;
+            const uint8_t* b = hll + (long long)pr.y * nreg;
+            if (nreg == 16384) {
+                // p = 14: both rows (2 x 16 KiB) are requested up front -- 32 x 16-B loads in flight per lane --
+                // before any LDS work starts; the kernel is bound by bytes in flight otherwise
+                const uint4* a4 = reinterpret_cast<const uint4*>(a);
+                const uint4* b4 = reinterpret_cast<const uint4*>(b);
+                uint4 xa[16], xb[16];
+#pragma unroll
+                for (int it = 0; it < 16; ++it) { xa[it] = a4[it * kWave + lane]; xb[it] = b4[it * kWave + lane]; }
+#pragma unroll
+                for (int it = 0; it < 16; ++it) {
+                    hist_add_word(col, max_u8x4(xa[it].x, xb[it].x));
+                    hist_add_word(col, max_u8x4(xa[it].y, xb[it].y));
+                    hist_add_word(col, max_u8x4(xa[it].z, xb[it].z));
+                    hist_add_word(col, max_u8x4(xa[it].w, xb[it].w));
+                }
+            } else if (nreg >= 1024) {
+                const uint4* a4 = reinterpret_cast<const uint4*>(a);
+                const uint4* b4 = reinterpret_cast<const uint4*>(b);
+                const int iters = (int)(nreg / (16 * kWave));
+                for (int it = 0; it < iters; ++it) {
+                    uint4 x = a4[it * kWave + lane], y = b4[it * kWave + lane];
+                    hist_add_word(col, max_u8x4(x.x, y.x));
+                    hist_add_word(col, max_u8x4(x.y, y.y));
+                    hist_add_word(col, max_u8x4(x.z, y.z));
+                    hist_add_word(col, max_u8x4(x.w, y.w));
+                }
+            } else {
+                for (long long t = lane; t < nreg; t += kWave) {
+                    uint32_t x = a[t], y = b[t];
+                    uint32_t v = (x > y ? x : y) & 63u;
+                    __hip_atomic_fetch_add(col + v * kWave, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+            }
+        }
+        __syncthreads();
+        if (active) {
+            // lane l sums bin l over the 64 lane-columns, rotated so that lanes hit distinct banks
+            uint32_t s = 0;
+            const uint32_t* rowp = my + lane * kWave;
+#pragma unroll 8
+            for (int t = 0; t < kWave; ++t) s += rowp[(t + lane) & (kWave - 1)];
+            counts[j * 64 + lane] = s;
+        }
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// ertl_select_kernel: one LANE per histogram.  The 64 histograms of a wave are staged in LDS
+// (pitch 65 -> conflict-free) because the estimator indexes them with run-time k.
+//   MODE 0: est[j] = estimate                                     (selhip_ertl_estimate, cards)
+//   MODE 1: t = estimate; J = ((double)e_x + (double)e_y - t)/t; if (J >= tau) append   (selection.cpp:286-288)
+//   MODE 2: like 1 but writes selhip_result_t{x,y,(float)J} (drop-in launchers)
+// ---------------------------------------------------------------------------------------------
+struct LdsCounts {
+    const uint32_t* base;       // &lds[lane]
+    __device__ __forceinline__ uint32_t operator[](int k) const { return base[k * 65]; }
+};
+
+template <bool FMA, int MODE>
+__global__ __launch_bounds__(kWave)
+void ertl_select_kernel(const uint32_t* __restrict__ counts, const u64* __restrict__ n_dev, u64 n_host, u64 cap,
+                        int p, double relerr_scaled,
+                        double* __restrict__ est,
+                        const selhip_int2_t* __restrict__ pairs, const u64* __restrict__ ecard, double tau,
+                        selhip_pair_t* __restrict__ results, u64 results_cap, PassCounters* __restrict__ pc,
+                        selhip_result_t* __restrict__ results_f32, int* __restrict__ out_count_i32,
+                        u64 chunk_off, u64 chunk_len) {
+    __shared__ uint32_t lds[64 * 65];
+    const int lane = threadIdx.x;
+    u64 n = n_dev ? *n_dev : n_host;
+    if (n > cap) n = cap;
+    n = n > chunk_off ? min(n - chunk_off, chunk_len) : 0;       // window of the list; counts indexed from its start
+    if (pairs) pairs += chunk_off;
+    if (est) est += chunk_off;
+    for (u64 base = (u64)blockIdx.x * kWave; base < n; base += (u64)gridDim.x * kWave) {
+        __syncthreads();
+        // row r of the tile = histogram base+r; lane = bin -> coalesced 256 B reads
+        for (int r = 0; r < kWave; ++r) {
+            u64 j = base + r;
+            uint32_t v = (j < n) ? counts[j * 64 + lane] : (lane == 0 ? (1u << p) : 0u);
+            lds[lane * 65 + r] = v;
+        }
+        __syncthreads();
+        const u64 j = base + lane;
+        LdsCounts c{lds + lane};
+        double t = selhip::ertl_ml_estimate<FMA>(c, (unsigned)p, (unsigned)(64 - p), relerr_scaled);
+        if (j < n) {
+            if constexpr (MODE == 0) {
+                est[j] = t;
+            } else {
+                const selhip_int2_t pr = pairs[j];
+                const double e1 = (double)ecard[pr.x], e2 = (double)ecard[pr.y];
+                const double jacc = (e1 + e2 - t) / t;                       // selection.cpp:287
+                if (jacc >= tau) {                                           // selection.cpp:288
+                    if constexpr (MODE == 1) {
+                        u64 idx = atomicAdd(&pc->n_results, 1ull);
+                        if (idx < results_cap) { results[idx].i = pr.x; results[idx].k = pr.y; results[idx].jaccard = jacc; }
+                    } else {
+                        int idx = atomicAdd(out_count_i32, 1);
+                        results_f32[idx].x = pr.x; results_f32[idx].y = pr.y; results_f32[idx].sim = (float)jacc;
+                    }
+                }
+            }
+        }
+    }
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// Auxiliary-HLL criteria (src/selection.cpp:152-173 hll_a, :206-227 hll_an; criteria_sketch.hpp:22-64).
+// enum_pairs_kernel lists the (CB-pruned) pair space of the rows explicitly -- only used when hll_a / hll_an
+// is the FIRST criterion; in the two-stage form (BASELINE config 5) the cheap smh_a join runs first and the
+// auxiliary criterion sees its survivors only: the selected set is the intersection either way.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock)
+void enum_pairs_kernel(int n, const int* __restrict__ hi, const PassCounters* __restrict__ pc_in,
+                       int row_begin, int row_end, int n_rows_grid,
+                       selhip_int2_t* __restrict__ out, u64 out_cap, PassCounters* __restrict__ pc) {
+    __shared__ selhip_int2_t app_lds[kWavesPerBlock * kAppendCap];
+    const int i = row_begin + (int)(blockIdx.x % n_rows_grid);
+    const int chunk = blockIdx.x / n_rows_grid;
+    if (i >= row_end) return;
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
+    const int kmin = max(i + 1, pc_in->z0p1 ? pc_in->z0p1 - 1 : n);
+    const int k = kmin + chunk * kBlock + (int)threadIdx.x;
+    WaveAppender app;
+    app.init(app_lds, wave, out, out_cap, &pc->n_aux_in);
+    app.push(k <= hi[i] && k < n, i, k, lane);
+    app.flush(lane);
+}
+
+// aux_filter_kernel<FMA, CRIT>: one LANE per pair; counts = union histogram of the two AUXILIARY sketches.
+//   CRIT 1 (hll_a):  t_hat = (size_t)U;  t+ = t_hat / (1 + Z*sigma_p);  K+ = ((1+gamma)*e_k - t+)/t+ >= tau
+//   CRIT 2 (hll_an): J = ((double)(e_i+e_k) - U)/U;  C = min(1, (1+Z*sigma_p)*e_k/U) * (1+gamma) * S;  J + C >= tau
+// zs = (double)(float)(Z*sigma_p) and S (= zs for order_n = 1) are computed on the host in float/double exactly as
+// criteria_sketch.hpp:7-20,25-31,39-40 do.  FMA flavour: g++ fuses (1+gamma)*card_B - t_hat_mas (criteria_sketch.hpp:41).
+template <bool FMA, int CRIT>
+__global__ __launch_bounds__(kWave)
+void aux_filter_kernel(const uint32_t* __restrict__ counts, const selhip_int2_t* __restrict__ pairs,
+                       const u64* __restrict__ n_dev, u64 chunk_off, u64 chunk_len, u64 cap,
+                       int p_aux, double relerr_scaled, const u64* __restrict__ ecard, double tau,
+                       double zs, double S_sum,
+                       selhip_int2_t* __restrict__ out, u64 out_cap, u64* __restrict__ out_count) {
+    __shared__ uint32_t lds[64 * 65];
+    __shared__ selhip_int2_t app_lds[kAppendCap];
+    const int lane = threadIdx.x;
+    u64 total = *n_dev;
+    if (total > cap) total = cap;
+    const u64 n = total > chunk_off ? min(total - chunk_off, chunk_len) : 0;     // pairs of this chunk
+    WaveAppender app;
+    app.init(app_lds, 0, out, out_cap, out_count);
+    for (u64 base = (u64)blockIdx.x * kWave; base < n; base += (u64)gridDim.x * kWave) {
+        __syncthreads();
+        for (int r = 0; r < kWave; ++r) {
+            u64 j = base + r;
+            lds[lane * 65 + r] = (j < n) ? counts[j * 64 + lane] : (lane == 0 ? (1u << p_aux) : 0u);
+        }
+        __syncthreads();
+        const u64 j = base + lane;
+        LdsCounts c{lds + lane};
+        const double U = selhip::ertl_ml_estimate<FMA>(c, (unsigned)p_aux, (unsigned)(64 - p_aux), relerr_scaled);
+        bool sel = false;
+        selhip_int2_t pr{0, 0};
+        if (j < n) {
+            pr = pairs[chunk_off + j];
+            const u64 ea = ecard[pr.x], eb = ecard[pr.y];
+            const double gamma = (double)ea / (double)eb;                         // criteria_sketch.hpp:24,38
+            if constexpr (CRIT == 1) {
+                const double t_hat = (double)(u64)(long long)U;                   // size_t t_hat = union_size()  (:61)
+                const double t_mas = t_hat / (1.0 + zs);                          // :40
+                const double K = selhip::muladd<FMA>(1.0 + gamma, (double)eb, -t_mas) / t_mas;   // :41
+                sel = K >= tau;                                                   // :63
+            } else {
+                const double J = ((double)(ea + eb) - U) / U;                     // :55
+                const double candv = (1.0 + zs) * (double)eb / U;                 // :32
+                const double minimo = candv < 1.0 ? candv : 1.0;                  // std::min(1.0, .)
+                const double C = minimo * (1 + gamma) * S_sum;                    // :33
+                sel = (J + C) >= tau;                                             // :57
+            }
+        }
+        app.push(sel, pr.x, pr.y, lane);
+    }
+    app.flush(lane);
+}
+
+}  // namespace

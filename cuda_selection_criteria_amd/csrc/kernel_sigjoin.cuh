@@ -1,0 +1,153 @@
+// kernel_sigjoin.cuh -- stage 1, ALGO_SIG: band signatures, all-pairs signature join (DPP broadcast), exact verification.
+// Part of libselhip.so; included by selection_kernels.hip only (one translation unit, anonymous namespace).
+#pragma once
+
+namespace {
+
+// =============================================================================================
+// ALGO_SIG -- stage 1 as a signature join (exact):
+//   a pair passes smh_a iff SOME band of r buckets is entirely equal (criteria_sketch.hpp:66-81).  Equal bands
+//   have equal 32-bit signatures (a hash of the band's r u64 values), so "some band signature equal" is a
+//   necessary condition; pairs that meet it are CANDIDATES and are verified with the literal predicate on the
+//   full sketches (verify_kernel).  A hash collision only adds a candidate that the verification rejects
+//   (expected n_bands * 2^-32 per pair), it can never drop a pair: the survivor set is identical to the
+//   stream kernel's.  The all-pairs part then costs n_bands 32-bit compares per pair instead of m 64-bit ones.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ u64 mix64(u64 x) {
+    x ^= x >> 30; x *= 0xBF58476D1CE4E5B9ull;
+    x ^= x >> 27; x *= 0x94D049BB133111EBull;
+    x ^= x >> 31;
+    return x;
+}
+
+// sig_build_kernel: one thread per bucket, coalesced 8-B loads; the r lanes of a band add their position-salted
+// mixes with xor-shuffles (r <= 64) -- or one thread walks the band (r > 64).  Writes both layouts:
+//   sigQ[g][NB] (query-major, read with scalar loads) and sigT[b][n_pad] (band-major, lane = candidate).
+__global__ __launch_bounds__(kBlock)
+void sig_build_kernel(const u64* __restrict__ aux, int n, int m, int r, int nb, int n_pad,
+                      uint32_t* __restrict__ sigQ, uint32_t* __restrict__ sigT) {
+    if (r <= kWave) {
+        const long long t = (long long)blockIdx.x * kBlock + threadIdx.x;      // global bucket index
+        const long long total = (long long)n * m;
+        u64 h = 0;
+        int j = 0;
+        if (t < total) {
+            j = (int)(t % r);                                                  // position inside the band
+            h = mix64(aux[t] + 0x9E3779B97F4A7C15ull * (u64)(j + 1));
+        }
+        for (int s = 1; s < r; s <<= 1) {                                      // r is a power of two here
+            h += __shfl_xor(h, s, kWave);
+        }
+        if (t < total && j == 0) {
+            const int g = (int)(t / m);
+            const int b = (int)((t % m) / r);
+            const uint32_t sig = (uint32_t)(h ^ (h >> 32));
+            sigQ[(long long)g * nb + b] = sig;
+            sigT[(long long)b * n_pad + g] = sig;
+        }
+    } else {
+        const long long t = (long long)blockIdx.x * kBlock + threadIdx.x;      // (genome, band)
+        if (t >= (long long)n * nb) return;
+        const int g = (int)(t / nb), b = (int)(t % nb);
+        const u64* v = aux + (long long)g * m + (long long)b * r;
+        u64 h = 0;
+        for (int j = 0; j < r; ++j) h += mix64(v[j] + 0x9E3779B97F4A7C15ull * (u64)(j + 1));
+        const uint32_t sig = (uint32_t)(h ^ (h >> 32));
+        sigQ[(long long)g * nb + b] = sig;
+        sigT[(long long)b * n_pad + g] = sig;
+    }
+}
+
+// sig_join_kernel<NB>: all-pairs "some band signature equal", entirely on the vector unit.
+//   lane = candidate k: its NB signatures live in VGPRs c[0..NB)            (loaded once per wave)
+//   queries come 16 at a time: lane l holds the signatures of query i16 + (l & 15) in qv[0..NB) (the four
+//   16-lane rows hold the same 16 queries); query j of the batch is broadcast to every lane by the DPP
+//   modifier row_newbcast:j ON the xor itself (v_xor_b32_dpp), so a band compare costs
+//       t = c[b] ^ bcast_j(qv[b]);  acc = min(acc, t)          (v_xor_b32_dpp + v_min_u32 / v_min3_u32)
+//   with no LDS, scalar-cache or SGPR traffic in the inner loop; acc == 0 iff some band matched.
+// Three earlier forms measured 0.5-0.65 ms on cfg3 and are recorded in DESIGN.md section 4: v_cmp_eq_u32 -> SGPR
+// mask -> s_or_b64 per band; query signatures streamed through scalar loads (the scalar-cache miss path
+// sustains ~0.5 B/clk/CU); query tile in LDS read back with broadcast ds_read_b128 (latency-bound at the
+// occupancy its registers allow).
+template <int J>
+__device__ __forceinline__ uint32_t dpp_row_bcast(uint32_t x) {
+    // DPP_ROW_NEWBCAST (gfx90a+): every lane reads lane J of its own 16-lane row
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x150 + J, 0xF, 0xF, true);
+}
+
+template <int NB, int J>
+__device__ __forceinline__ void join_one_query(const uint32_t (&c)[NB], const uint32_t (&qv)[NB], int i, int i_hi,
+                                               int k, int lane, int z0, int n, const int* __restrict__ hi,
+                                               WaveAppender& app) {
+    // two independent chains of v_min3_u32(acc, x, y): 1.5 VALU per band
+    uint32_t acc0 = 0xFFFFFFFFu, acc1 = 0xFFFFFFFFu;
+#pragma unroll
+    for (int b = 0; b < NB; b += 4) {
+        acc0 = min(min(acc0, c[b] ^ dpp_row_bcast<J>(qv[b])), c[b + 1] ^ dpp_row_bcast<J>(qv[b + 1]));
+        acc1 = min(min(acc1, c[b + 2] ^ dpp_row_bcast<J>(qv[b + 2])), c[b + 3] ^ dpp_row_bcast<J>(qv[b + 3]));
+    }
+    const u64 mm = __ballot(min(acc0, acc1) == 0u);
+    if (mm && i < i_hi) {
+        const int lo = max(i + 1, z0);
+        const int hk = min(hi[i], n - 1);
+        app.push(((mm >> lane) & 1ull) && k >= lo && k <= hk, i, k, lane);
+    }
+}
+
+template <int NB>
+__global__ __launch_bounds__(kBlock)
+void sig_join_kernel(const uint32_t* __restrict__ sigT, int n, int n_pad,
+                     const int* __restrict__ hi, const PassCounters* __restrict__ pc_in,
+                     int row_begin, int row_end, int n_tiles, int group_base, int qt,
+                     selhip_int2_t* __restrict__ cand, u64 cand_cap, PassCounters* __restrict__ pc) {
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
+    const int tile = blockIdx.x % n_tiles;
+    const int grp = group_base + (blockIdx.x / n_tiles) * kWavesPerBlock + wave;
+    const int k_base = grp * kWave;
+    if (k_base >= n) return;
+    const int z0 = pc_in->z0p1 ? pc_in->z0p1 - 1 : n;
+    const int k_last = k_base + kWave - 1;
+    const int i_lo = row_begin + tile * qt;                                   // qt is a multiple of 16
+    const int i_hi = min(min(i_lo + qt, row_end), k_last);                    // need i < k for some lane
+    if (i_lo >= i_hi || k_last < z0) return;
+    if (hi[i_hi - 1] < k_base) return;                                        // hi is non-decreasing
+
+    __shared__ selhip_int2_t app_lds[kWavesPerBlock * kAppendCap];
+    WaveAppender app;
+    app.init(app_lds, wave, cand, cand_cap, &pc->n_candidates);
+    const int k = k_base + lane;                                              // < n_pad
+    uint32_t c[NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) c[b] = sigT[(long long)b * n_pad + k];
+
+    for (int i16 = i_lo; i16 < i_hi; i16 += 16) {
+        const int qi = min(i16 + (lane & 15), n_pad - 1);
+        uint32_t qv[NB];
+#pragma unroll
+        for (int b = 0; b < NB; ++b) qv[b] = sigT[(long long)b * n_pad + qi];
+#define SELHIP_JQ(J) join_one_query<NB, J>(c, qv, i16 + J, i_hi, k, lane, z0, n, hi, app);
+        SELHIP_JQ(0) SELHIP_JQ(1) SELHIP_JQ(2) SELHIP_JQ(3) SELHIP_JQ(4) SELHIP_JQ(5) SELHIP_JQ(6) SELHIP_JQ(7)
+        SELHIP_JQ(8) SELHIP_JQ(9) SELHIP_JQ(10) SELHIP_JQ(11) SELHIP_JQ(12) SELHIP_JQ(13) SELHIP_JQ(14) SELHIP_JQ(15)
+#undef SELHIP_JQ
+    }
+    app.flush(lane);
+}
+
+// verify_kernel: the literal smh_a on every candidate (one lane per candidate), survivors compacted.
+__global__ __launch_bounds__(kBlock)
+void verify_kernel(const u64* __restrict__ aux, int m, int n_rows, int n_bands,
+                   const selhip_int2_t* __restrict__ cand, const u64* __restrict__ n_cand_dev, u64 cand_cap,
+                   selhip_int2_t* __restrict__ surv, u64 surv_cap, PassCounters* __restrict__ pc) {
+    u64 n_cand = *n_cand_dev;
+    if (n_cand > cand_cap) n_cand = cand_cap;
+    for (u64 j = (u64)blockIdx.x * kBlock + threadIdx.x; j < n_cand; j += (u64)gridDim.x * kBlock) {
+        const selhip_int2_t pr = cand[j];
+        if (smh_a_lane(aux + (long long)pr.x * m, aux + (long long)pr.y * m, n_rows, n_bands)) {
+            u64 idx = atomicAdd(&pc->n_survivors, 1ull);
+            if (idx < surv_cap) surv[idx] = pr;
+        }
+    }
+}
+
+}  // namespace

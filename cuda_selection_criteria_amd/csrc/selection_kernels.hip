@@ -5,18 +5,16 @@
 //   include/criteria_sketch_cuda.cuh:11-65 (device CB / smh_a / hll_union_card)
 // with the RESULT SEMANTICS of the CPU path src/selection.cpp:270-291 (see include/selection_hip.h).
 //
-// Kernels (all integer except the estimator):
-//   cb_bounds_kernel        e_i = (size_t)card_i, CB cut-off hi(i) by binary search (CB is monotone on
-//                           sorted cards, so the reference's `break` == a per-row upper bound)
-//   smh_stream_kernel       stage 1, "stream" algorithm: a tile of Q query sketches is staged in LDS and
-//                           held in VGPRs, candidate sketches are streamed row-major with 16 B/lane
-//                           coalesced loads, v_cmp_eq_u64 lane masks are folded on the scalar unit into
-//                           the band predicate of criteria_sketch.hpp:66-81
-//   smh_generic_kernel      any (m, n_rows, n_bands): lane-per-candidate, used for m < 128 or odd shapes
-//   hll_union_hist_kernel   stage 2a: per surviving pair, histogram of max(reg_i, reg_k) (hll.h:1188-1204)
-//   ertl_select_kernel      stage 2b: lane-per-pair Ertl MLE (hll.h:629-688) + Jaccard test (selection.cpp:286-288)
-//   pairlist_kernel         self-contained wave-per-pair path behind the drop-in launch_kernel_* entry points
-//   synth_kernel            synthetic sketches generated in HBM (csrc/synth.hpp)
+// This file holds the HOST side of the library (context, dispatch, C ABI).  The kernels live in the headers it
+// includes (one translation unit; all integer except the estimator; no MFMA):
+//   common.cuh          launch constants, per-pass counters, WaveAppender (LDS-staged appends, one atomic per flush)
+//   kernel_bounds.cuh   cb_bounds_kernel      e_i = (size_t)card_i, CB cut-off hi(i), first non-zero rank
+//   kernel_stream.cuh   smh_stream_kernel     stage 1 ALGO_STREAM: query tile in LDS/VGPRs, candidates streamed row-major,
+//                                             v_cmp_eq_u64 lane masks folded on the scalar unit; smh_generic_kernel
+//   kernel_sigjoin.cuh  sig_build / sig_join / verify   stage 1 ALGO_SIG: all-pairs band-signature join (DPP broadcast) + exact verify
+//   kernel_hll.cuh      hll_union_hist_kernel, ertl_select_kernel (stage 2), enum_pairs / aux_filter (hll_a, hll_an)
+//   kernel_pairlist.cuh explicit pair lists (drop-in launch_kernel_* path, test building blocks)
+//   kernel_sketch.cuh   synth_kernel, sketch_build_kernel (build_sketch on the GPU), permute_rows
 //
 // Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off (see csrc/Makefile).
 #include <hip/hip_runtime.h>
@@ -35,1050 +33,15 @@
 #include "ertl_mle.hpp"
 #include "synth.hpp"
 
+#include "common.cuh"
+#include "kernel_bounds.cuh"
+#include "kernel_stream.cuh"
+#include "kernel_sigjoin.cuh"
+#include "kernel_hll.cuh"
+#include "kernel_pairlist.cuh"
+#include "kernel_sketch.cuh"
+
 namespace {
-
-using u64 = unsigned long long;
-typedef u64 u64x2 __attribute__((ext_vector_type(2)));
-
-constexpr int kWave = 64;
-constexpr int kBlock = 256;            // 4 waves
-constexpr int kWavesPerBlock = kBlock / kWave;
-constexpr int kChunk = 256;            // candidates per stage-1 block
-constexpr int kQueryVgprBudget = 32;   // u64x2 query registers per lane  (Q * NCH)
-
-// ---------------------------------------------------------------------------------------------
-// device-side counters of one pass
-// ---------------------------------------------------------------------------------------------
-struct PassCounters {
-    u64 n_survivors;     // stage-1 survivors appended (may exceed capacity: exact count, stores clipped)
-    u64 n_results;       // selected pairs appended (same convention)
-    u64 n_evaluated;     // pairs inside the (triangular / CB-banded) pair space of this pass
-    u64 n_candidates;    // ALGO_SIG: signature-join candidates
-    u64 n_aux_in;        // pairs handed to the auxiliary-HLL criterion (hll_a / hll_an)
-    u64 n_final;         // pairs handed to the final HLL-14 Jaccard stage
-    int z0;              // first rank with e != 0
-    int unsorted;        // set if cards are not ascending
-    int pad[2];
-};
-
-
-// ---------------------------------------------------------------------------------------------
-// WaveAppender: per-wave staging of output records in LDS, flushed with ONE global atomic per >= 64 records.
-// A returning atomic on a single address sustains only ~90 operations/us chip-wide (MI355X_MICROARCH.md,
-// row "dequeue"), so appending survivors one atomicAdd at a time caps a pass at ~90 survivors/us
-// (45 000 survivors = 0.5 ms -- measured: it was THE cost of the first signature-join kernels).
-// ---------------------------------------------------------------------------------------------
-constexpr int kAppendCap = 2 * kWave;          // count < 64 before a push, a push adds <= 64
-
-struct WaveAppender {
-    selhip_int2_t* buf;        // this wave's LDS staging area [kAppendCap]
-    int count;                 // wave-uniform
-    selhip_int2_t* out;
-    u64 out_cap;
-    u64* out_count;
-
-    __device__ __forceinline__ void init(selhip_int2_t* lds_block, int wave, selhip_int2_t* o, u64 cap, u64* cnt) {
-        buf = lds_block + wave * kAppendCap; count = 0; out = o; out_cap = cap; out_count = cnt;
-    }
-    __device__ __forceinline__ void flush(int lane) {
-        if (count == 0) return;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        u64 base = 0;
-        if (lane == 0) base = atomicAdd(out_count, (u64)count);
-        base = ((u64)__builtin_amdgcn_readfirstlane((int)(base >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)base);
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        for (int t = lane; t < count; t += kWave)
-            if (base + (u64)t < out_cap) out[base + (u64)t] = buf[t];
-        count = 0;
-    }
-    // lanes with pred push (x,y); the call must be wave-uniformly reached
-    __device__ __forceinline__ void push(bool pred, int x, int y, int lane) {
-        const u64 m = __ballot(pred);
-        if (m == 0) return;
-        if (pred) {
-            const int off = count + (int)__popcll(m & ((1ull << lane) - 1ull));
-            buf[off].x = x; buf[off].y = y;
-        }
-        count += (int)__popcll(m);
-        if (count >= kWave) flush(lane);
-    }
-    // wave-uniform single record
-    __device__ __forceinline__ void push_uniform(int x, int y, int lane) {
-        if (lane == 0) { buf[count].x = x; buf[count].y = y; }
-        count += 1;
-        if (count >= kWave) flush(lane);
-    }
-};
-
-// ---------------------------------------------------------------------------------------------
-// cb_bounds_kernel: one thread per genome rank.
-//   ecard[i] = (size_t)cards[i]                                         (selection.cpp:275,280)
-//   hi[i]    = last k such that CB(tau, e_i, e_k) holds, or N-1 without CB  (criteria_sketch.hpp:45-49;
-//              the loop `break`s at the first failing k (selection.cpp:282-283); e is ascending so the
-//              predicate is monotone and the break is exactly "k <= hi(i)")
-//   z0       = first rank with e != 0  (`if(e2 == 0) continue`, selection.cpp:281)
-// ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ bool cb_pred(double tau, u64 e1, u64 e2) {
-    double gamma = (double)e1 / (double)e2;      // criteria_sketch.hpp:47 (size_t -> double, IEEE divide)
-    return gamma >= tau;
-}
-
-__global__ void cb_bounds_kernel(const double* __restrict__ cards, int n, double tau, int use_cb,
-                                 int row_begin, int row_end, u64* __restrict__ ecard, int* __restrict__ hi,
-                                 PassCounters* __restrict__ pc) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    double c = cards[i];
-    u64 e1 = selhip::trunc_card(c);
-    ecard[i] = e1;
-    if (i > 0) {
-        double cp = cards[i - 1];
-        if (c < cp) pc->unsorted = 1;
-        if (e1 != 0 && selhip::trunc_card(cp) == 0) pc->z0 = i;
-    } else if (e1 != 0) {
-        pc->z0 = 0;
-    }
-    int h = n - 1;
-    if (use_cb) {
-        // largest k in (i, n) with (e_k == 0 || CB(e1, e_k)); predicate is true on a prefix
-        int lo = i, hi_ = n - 1;      // invariant: pred(lo) true (k = i itself counts as true), answer in [lo, hi_]
-        while (lo < hi_) {
-            int mid = lo + (hi_ - lo + 1) / 2;
-            u64 e2 = selhip::trunc_card(cards[mid]);
-            bool ok = (e2 == 0) || cb_pred(tau, e1, e2);
-            if (ok) lo = mid; else hi_ = mid - 1;
-        }
-        h = lo;
-    }
-    hi[i] = h;
-    if (i >= row_begin && i < row_end) {
-        // pairs of this row inside the pair space: k in [max(i+1, z0'), h]; z0 may not be published yet,
-        // so count candidates with e_k != 0 directly from the sorted property: e_k == 0 only for k < z0.
-        // first k > i with e_k != 0: if e1 != 0 it is i+1, else binary search.
-        int first = i + 1;
-        if (e1 == 0) {
-            int lo = i + 1, hi2 = n;          // first index in [i+1, n) with e != 0
-            while (lo < hi2) {
-                int mid = lo + (hi2 - lo) / 2;
-                if (selhip::trunc_card(cards[mid]) != 0) hi2 = mid; else lo = mid + 1;
-            }
-            first = lo;
-        }
-        long long cnt = (long long)h - first + 1;
-        if (cnt > 0) atomicAdd(&pc->n_evaluated, (u64)cnt);
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
-// Band predicate on lane masks.  A candidate chunk of 128 buckets is held as one u64x2 per lane:
-// lane l owns buckets (2l, 2l+1).  m0/m1 are the v_cmp_eq_u64 lane masks of the even/odd bucket.
-// A band of r = 2^LOG2R consecutive buckets is, for r >= 2, r/2 consecutive lanes of (m0 & m1).
-// Returns a mask with a bit set for every fully equal band (r <= 128).
-// ---------------------------------------------------------------------------------------------
-template <int HALF>
-__host__ __device__ constexpr u64 align_mask() {
-    // one bit at every multiple of HALF
-    u64 v = 0;
-    for (int b = 0; b < 64; b += HALF) v |= 1ull << b;
-    return v;
-}
-
-template <int LOG2R>
-__device__ __forceinline__ u64 band_fold(u64 m0, u64 m1) {
-    if constexpr (LOG2R == 0) {
-        return m0 | m1;
-    } else {
-        constexpr int HALF = 1 << (LOG2R - 1);
-        u64 t = m0 & m1;
-#pragma unroll
-        for (int s = 1; s < HALF; s <<= 1) t &= t >> s;
-        return t & align_mask<HALF>();
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
-// smh_stream_kernel<NCH, LOG2R>: m = 128*NCH buckets, bands of 2^LOG2R rows (LOG2R == 7: r >= 128,
-// runtime r_rt, a band covers r_rt/128 whole chunks).
-//   block  = 4 waves; one block = (query tile of Q = 32/NCH rows) x (chunk of kChunk candidates)
-//   LDS    = the Q query sketches (32 KiB), staged once per block, then copied to VGPRs by each wave
-//   stream = each wave walks its candidates (stride 4), NCH x global_load_dwordx4 per candidate
-// blockIdx.x -> (tile = b % n_tiles, chunk = b / n_tiles): blocks b and b+8 (same XCD under round-robin
-// dispatch) work on the same candidate chunk, so the chunk is served by that XCD's L2.
-// ---------------------------------------------------------------------------------------------
-template <int NCH, int LOG2R>
-__global__ __launch_bounds__(kBlock, (NCH <= 4 ? 3 : 2))      // 3 waves/SIMD = at most 168 VGPRs (measured: 2 waves cost 17 %)
-void smh_stream_kernel(const u64x2* __restrict__ aux, int n, int r_rt,
-                       const int* __restrict__ hi, const PassCounters* __restrict__ pc_in,
-                       int row_begin, int row_end, int n_tiles, int chunk_base,
-                       selhip_int2_t* __restrict__ surv, u64 surv_cap, PassCounters* __restrict__ pc) {
-    constexpr int Q = kQueryVgprBudget / NCH;
-    constexpr int ROWV = NCH * kWave;                 // u64x2 per sketch row
-    __shared__ u64x2 qs[Q * ROWV];
-    __shared__ selhip_int2_t app_lds[kWavesPerBlock * kAppendCap];
-
-    const int tile = blockIdx.x % n_tiles;
-    const int chunk = blockIdx.x / n_tiles;
-    const int i0 = row_begin + tile * Q;
-    const int i_last = min(i0 + Q, row_end) - 1;
-    const int z0 = pc_in->z0;
-    const int k0 = chunk_base + chunk * kChunk;
-    const int kmax = hi[i_last];                      // hi is non-decreasing in i
-    const int kmin = max(i0 + 1, z0);
-    if (k0 > kmax || k0 + kChunk - 1 < kmin) return;
-
-    // stage the query tile: rows i0 .. i0+Q-1 are contiguous in memory
-    {
-        const long long base = (long long)i0 * ROWV;
-        const long long limit = (long long)n * ROWV;
-        for (int t = threadIdx.x; t < Q * ROWV; t += kBlock) {
-            long long src = base + t;
-            if (src >= limit) src = limit - 1;        // rows past the end: never valid, any data will do
-            qs[t] = aux[src];
-        }
-    }
-    __syncthreads();
-
-    const int lane = threadIdx.x & (kWave - 1);
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);     // wave-uniform -> SGPR loop counter
-    u64x2 q[Q][NCH];
-#pragma unroll
-    for (int a = 0; a < Q; ++a)
-#pragma unroll
-        for (int c = 0; c < NCH; ++c) q[a][c] = qs[(a * NCH + c) * kWave + lane];
-
-    const int k_end = min(min(k0 + kChunk, n), kmax + 1);
-    int k = max(k0, kmin) + wave;
-    if (k >= k_end) return;
-    WaveAppender app;
-    app.init(app_lds, wave, surv, surv_cap, &pc->n_survivors);
-    // software pipeline: the next candidate's loads are in flight while the current one is compared
-    u64x2 cand[NCH], nxt[NCH];
-    {
-        const u64x2* row = aux + (long long)k * ROWV + lane;
-#pragma unroll
-        for (int c = 0; c < NCH; ++c) nxt[c] = row[c * kWave];
-    }
-    for (; k < k_end; k += kWavesPerBlock) {
-#pragma unroll
-        for (int c = 0; c < NCH; ++c) cand[c] = nxt[c];
-        {
-            const int kn = min(k + kWavesPerBlock, k_end - 1);                // clamped: last prefetch re-reads a valid row
-            const u64x2* row = aux + (long long)kn * ROWV + lane;
-#pragma unroll
-            for (int c = 0; c < NCH; ++c) nxt[c] = row[c * kWave];
-        }
-
-#pragma unroll
-        for (int a = 0; a < Q; ++a) {
-            bool pass;
-            if constexpr (LOG2R < 7) {
-                u64 acc = 0;
-#pragma unroll
-                for (int c = 0; c < NCH; ++c) {
-                    u64 m0 = __ballot(cand[c].x == q[a][c].x);
-                    u64 m1 = __ballot(cand[c].y == q[a][c].y);
-                    acc |= band_fold<LOG2R>(m0, m1);
-                }
-                pass = acc != 0;
-            } else {
-                // r_rt >= 128: a band is r_rt/128 consecutive chunks, all 128 buckets of each equal
-                const int G = r_rt >> 7;
-                pass = false;
-                bool run = true;
-#pragma unroll
-                for (int c = 0; c < NCH; ++c) {
-                    u64 m0 = __ballot(cand[c].x == q[a][c].x);
-                    u64 m1 = __ballot(cand[c].y == q[a][c].y);
-                    bool full = (m0 & m1) == ~0ull;
-                    if ((c % G) == 0) run = true;
-                    run = run && full;
-                    if ((c % G) == G - 1 && run) pass = true;
-                }
-            }
-            if (pass) {
-                const int i = i0 + a;
-                if (i < row_end && k > i && k >= z0 && k <= hi[i]) app.push_uniform(i, k, lane);
-            }
-        }
-    }
-    app.flush(lane);
-}
-
-// ---------------------------------------------------------------------------------------------
-// smh_a for one pair evaluated by ONE LANE (any m, rows, bands): criteria_sketch.hpp:66-81 literally.
-// ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ bool smh_a_lane(const u64* __restrict__ v1, const u64* __restrict__ v2,
-                                           int n_rows, int n_bands) {
-    for (int b = 0; b < n_bands; ++b) {
-        const u64* x = v1 + (long long)b * n_rows;
-        const u64* y = v2 + (long long)b * n_rows;
-        int j = 0;
-        while (j < n_rows && x[j] == y[j]) ++j;
-        if (j == n_rows) return true;
-    }
-    return false;
-}
-
-// generic stage 1: block = 256 lanes = 256 candidates of one query row; grid = (chunks, rows)
-__global__ __launch_bounds__(kBlock)
-void smh_generic_kernel(const u64* __restrict__ aux, int n, int m, int n_rows, int n_bands,
-                        const int* __restrict__ hi, const PassCounters* __restrict__ pc_in,
-                        int row_begin, int row_end, int n_rows_grid,
-                        selhip_int2_t* __restrict__ surv, u64 surv_cap, PassCounters* __restrict__ pc) {
-    __shared__ selhip_int2_t app_lds[kWavesPerBlock * kAppendCap];
-    const int i = row_begin + (int)(blockIdx.x % n_rows_grid);
-    const int chunk = blockIdx.x / n_rows_grid;
-    if (i >= row_end) return;
-    const int lane = threadIdx.x & (kWave - 1);
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
-    const int z0 = pc_in->z0;
-    const int kmin = max(i + 1, z0);
-    const int kmax = hi[i];
-    const int k = kmin + chunk * kBlock + (int)threadIdx.x;
-    const bool in_range = k <= kmax && k < n;
-    const bool ok = in_range && smh_a_lane(aux + (long long)i * m, aux + (long long)k * m, n_rows, n_bands);
-    WaveAppender app;
-    app.init(app_lds, wave, surv, surv_cap, &pc->n_survivors);
-    app.push(ok, i, k, lane);
-    app.flush(lane);
-}
-
-
-// =============================================================================================
-// ALGO_SIG -- stage 1 as a signature join (exact):
-//   a pair passes smh_a iff SOME band of r buckets is entirely equal (criteria_sketch.hpp:66-81).  Equal bands
-//   have equal 32-bit signatures (a hash of the band's r u64 values), so "some band signature equal" is a
-//   necessary condition; pairs that meet it are CANDIDATES and are verified with the literal predicate on the
-//   full sketches (verify_kernel).  A hash collision only adds a candidate that the verification rejects
-//   (expected n_bands * 2^-32 per pair), it can never drop a pair: the survivor set is identical to the
-//   stream kernel's.  The all-pairs part then costs n_bands 32-bit compares per pair instead of m 64-bit ones.
-// ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ u64 mix64(u64 x) {
-    x ^= x >> 30; x *= 0xBF58476D1CE4E5B9ull;
-    x ^= x >> 27; x *= 0x94D049BB133111EBull;
-    x ^= x >> 31;
-    return x;
-}
-
-// sig_build_kernel: one thread per bucket, coalesced 8-B loads; the r lanes of a band add their position-salted
-// mixes with xor-shuffles (r <= 64) -- or one thread walks the band (r > 64).  Writes both layouts:
-//   sigQ[g][NB] (query-major, read with scalar loads) and sigT[b][n_pad] (band-major, lane = candidate).
-__global__ __launch_bounds__(kBlock)
-void sig_build_kernel(const u64* __restrict__ aux, int n, int m, int r, int nb, int n_pad,
-                      uint32_t* __restrict__ sigQ, uint32_t* __restrict__ sigT) {
-    if (r <= kWave) {
-        const long long t = (long long)blockIdx.x * kBlock + threadIdx.x;      // global bucket index
-        const long long total = (long long)n * m;
-        u64 h = 0;
-        int j = 0;
-        if (t < total) {
-            j = (int)(t % r);                                                  // position inside the band
-            h = mix64(aux[t] + 0x9E3779B97F4A7C15ull * (u64)(j + 1));
-        }
-        for (int s = 1; s < r; s <<= 1) {                                      // r is a power of two here
-            h += __shfl_xor(h, s, kWave);
-        }
-        if (t < total && j == 0) {
-            const int g = (int)(t / m);
-            const int b = (int)((t % m) / r);
-            const uint32_t sig = (uint32_t)(h ^ (h >> 32));
-            sigQ[(long long)g * nb + b] = sig;
-            sigT[(long long)b * n_pad + g] = sig;
-        }
-    } else {
-        const long long t = (long long)blockIdx.x * kBlock + threadIdx.x;      // (genome, band)
-        if (t >= (long long)n * nb) return;
-        const int g = (int)(t / nb), b = (int)(t % nb);
-        const u64* v = aux + (long long)g * m + (long long)b * r;
-        u64 h = 0;
-        for (int j = 0; j < r; ++j) h += mix64(v[j] + 0x9E3779B97F4A7C15ull * (u64)(j + 1));
-        const uint32_t sig = (uint32_t)(h ^ (h >> 32));
-        sigQ[(long long)g * nb + b] = sig;
-        sigT[(long long)b * n_pad + g] = sig;
-    }
-}
-
-// sig_join_kernel<NB>: all-pairs "some band signature equal", entirely on the vector unit.
-//   lane = candidate k: its NB signatures live in VGPRs c[0..NB)            (loaded once per wave)
-//   queries come 16 at a time: lane l holds the signatures of query i16 + (l & 15) in qv[0..NB) (the four
-//   16-lane rows hold the same 16 queries); query j of the batch is broadcast to every lane by the DPP
-//   modifier row_newbcast:j ON the xor itself (v_xor_b32_dpp), so a band compare costs
-//       t = c[b] ^ bcast_j(qv[b]);  acc = min(acc, t)          (v_xor_b32_dpp + v_min_u32 / v_min3_u32)
-//   with no LDS, scalar-cache or SGPR traffic in the inner loop; acc == 0 iff some band matched.
-// Three earlier forms measured 0.5-0.65 ms on cfg3 and are recorded in DESIGN.md section 4: v_cmp_eq_u32 -> SGPR
-// mask -> s_or_b64 per band; query signatures streamed through scalar loads (the scalar-cache miss path
-// sustains ~0.5 B/clk/CU); query tile in LDS read back with broadcast ds_read_b128 (latency-bound at the
-// occupancy its registers allow).
-template <int J>
-__device__ __forceinline__ uint32_t dpp_row_bcast(uint32_t x) {
-    // DPP_ROW_NEWBCAST (gfx90a+): every lane reads lane J of its own 16-lane row
-    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x150 + J, 0xF, 0xF, true);
-}
-
-template <int NB, int J>
-__device__ __forceinline__ void join_one_query(const uint32_t (&c)[NB], const uint32_t (&qv)[NB], int i, int i_hi,
-                                               int k, int lane, int z0, int n, const int* __restrict__ hi,
-                                               WaveAppender& app) {
-    // two independent chains of v_min3_u32(acc, x, y): 1.5 VALU per band
-    uint32_t acc0 = 0xFFFFFFFFu, acc1 = 0xFFFFFFFFu;
-#pragma unroll
-    for (int b = 0; b < NB; b += 4) {
-        acc0 = min(min(acc0, c[b] ^ dpp_row_bcast<J>(qv[b])), c[b + 1] ^ dpp_row_bcast<J>(qv[b + 1]));
-        acc1 = min(min(acc1, c[b + 2] ^ dpp_row_bcast<J>(qv[b + 2])), c[b + 3] ^ dpp_row_bcast<J>(qv[b + 3]));
-    }
-    const u64 mm = __ballot(min(acc0, acc1) == 0u);
-    if (mm && i < i_hi) {
-        const int lo = max(i + 1, z0);
-        const int hk = min(hi[i], n - 1);
-        app.push(((mm >> lane) & 1ull) && k >= lo && k <= hk, i, k, lane);
-    }
-}
-
-template <int NB>
-__global__ __launch_bounds__(kBlock)
-void sig_join_kernel(const uint32_t* __restrict__ sigT, int n, int n_pad,
-                     const int* __restrict__ hi, const PassCounters* __restrict__ pc_in,
-                     int row_begin, int row_end, int n_tiles, int group_base, int qt,
-                     selhip_int2_t* __restrict__ cand, u64 cand_cap, PassCounters* __restrict__ pc) {
-    const int lane = threadIdx.x & (kWave - 1);
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
-    const int tile = blockIdx.x % n_tiles;
-    const int grp = group_base + (blockIdx.x / n_tiles) * kWavesPerBlock + wave;
-    const int k_base = grp * kWave;
-    if (k_base >= n) return;
-    const int z0 = pc_in->z0;
-    const int k_last = k_base + kWave - 1;
-    const int i_lo = row_begin + tile * qt;                                   // qt is a multiple of 16
-    const int i_hi = min(min(i_lo + qt, row_end), k_last);                    // need i < k for some lane
-    if (i_lo >= i_hi || k_last < z0) return;
-    if (hi[i_hi - 1] < k_base) return;                                        // hi is non-decreasing
-
-    __shared__ selhip_int2_t app_lds[kWavesPerBlock * kAppendCap];
-    WaveAppender app;
-    app.init(app_lds, wave, cand, cand_cap, &pc->n_candidates);
-    const int k = k_base + lane;                                              // < n_pad
-    uint32_t c[NB];
-#pragma unroll
-    for (int b = 0; b < NB; ++b) c[b] = sigT[(long long)b * n_pad + k];
-
-    for (int i16 = i_lo; i16 < i_hi; i16 += 16) {
-        const int qi = min(i16 + (lane & 15), n_pad - 1);
-        uint32_t qv[NB];
-#pragma unroll
-        for (int b = 0; b < NB; ++b) qv[b] = sigT[(long long)b * n_pad + qi];
-#define SELHIP_JQ(J) join_one_query<NB, J>(c, qv, i16 + J, i_hi, k, lane, z0, n, hi, app);
-        SELHIP_JQ(0) SELHIP_JQ(1) SELHIP_JQ(2) SELHIP_JQ(3) SELHIP_JQ(4) SELHIP_JQ(5) SELHIP_JQ(6) SELHIP_JQ(7)
-        SELHIP_JQ(8) SELHIP_JQ(9) SELHIP_JQ(10) SELHIP_JQ(11) SELHIP_JQ(12) SELHIP_JQ(13) SELHIP_JQ(14) SELHIP_JQ(15)
-#undef SELHIP_JQ
-    }
-    app.flush(lane);
-}
-
-// verify_kernel: the literal smh_a on every candidate (one lane per candidate), survivors compacted.
-__global__ __launch_bounds__(kBlock)
-void verify_kernel(const u64* __restrict__ aux, int m, int n_rows, int n_bands,
-                   const selhip_int2_t* __restrict__ cand, const u64* __restrict__ n_cand_dev, u64 cand_cap,
-                   selhip_int2_t* __restrict__ surv, u64 surv_cap, PassCounters* __restrict__ pc) {
-    u64 n_cand = *n_cand_dev;
-    if (n_cand > cand_cap) n_cand = cand_cap;
-    for (u64 j = (u64)blockIdx.x * kBlock + threadIdx.x; j < n_cand; j += (u64)gridDim.x * kBlock) {
-        const selhip_int2_t pr = cand[j];
-        if (smh_a_lane(aux + (long long)pr.x * m, aux + (long long)pr.y * m, n_rows, n_bands)) {
-            u64 idx = atomicAdd(&pc->n_survivors, 1ull);
-            if (idx < surv_cap) surv[idx] = pr;
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
-// hll_union_hist_kernel: one wave per pair.  LDS holds a lane-private 64-bin histogram per wave
-// ([bin][lane], conflict-free ds_add_u32), reduced with a rotated column walk.
-// counts[j][0..63] = #registers whose max(reg_x, reg_y) equals the bin    (hll.h:1188-1204)
-// ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ uint32_t max_u8x4(uint32_t a, uint32_t b) {
-    // per-byte unsigned max without carries between bytes
-    uint32_t r = 0;
-#pragma unroll
-    for (int s = 0; s < 32; s += 8) {
-        uint32_t x = (a >> s) & 0xFF, y = (b >> s) & 0xFF;
-        r |= (x > y ? x : y) << s;
-    }
-    return r;
-}
-
-__device__ __forceinline__ void hist_add_word(uint32_t* __restrict__ col, uint32_t w) {
-#pragma unroll
-    for (int s = 0; s < 32; s += 8) {
-        uint32_t v = (w >> s) & 63u;              // register values are <= 64-p+1 < 64
-        __hip_atomic_fetch_add(col + v * kWave, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    }
-}
-
-__global__ __launch_bounds__(kBlock)
-void hll_union_hist_kernel(const uint8_t* __restrict__ hll, int p,
-                           const selhip_int2_t* __restrict__ pairs, const u64* __restrict__ n_pairs_dev,
-                           u64 n_pairs_host, u64 cap, uint32_t* __restrict__ counts,
-                           u64 chunk_off = 0, u64 chunk_len = ~0ull) {
-    __shared__ uint32_t hist[kWavesPerBlock][64 * kWave];     // 64 KiB
-    const int lane = threadIdx.x & (kWave - 1);
-    const int wave = threadIdx.x / kWave;
-    u64 n_pairs = n_pairs_dev ? *n_pairs_dev : n_pairs_host;
-    if (n_pairs > cap) n_pairs = cap;
-    // optional window [chunk_off, chunk_off + chunk_len) of the list; counts are indexed from the window start
-    n_pairs = n_pairs > chunk_off ? min(n_pairs - chunk_off, chunk_len) : 0;
-    pairs += chunk_off;
-    const long long nreg = 1ll << p;
-    uint32_t* my = hist[wave];
-    uint32_t* col = my + lane;
-
-    for (u64 base = (u64)blockIdx.x * kWavesPerBlock; base < n_pairs; base += (u64)gridDim.x * kWavesPerBlock) {
-        const u64 j = base + wave;
-        const bool active = j < n_pairs;
-        // zero this wave's histogram
-#pragma unroll 8
-        for (int b = 0; b < 64; ++b) col[b * kWave] = 0;
-        __syncthreads();
-        if (active) {
-            const selhip_int2_t pr = pairs[j];
-            const uint8_t* a = hll + (long long)pr.x * nreg;
-            const uint8_t* b = hll + (long long)pr.y * nreg;
-            if (nreg == 16384) {
-                // p = 14: both rows (2 x 16 KiB) are requested up front -- 32 x 16-B loads in flight per lane --
-                // before any LDS work starts; the kernel is bound by bytes in flight otherwise
-                const uint4* a4 = reinterpret_cast<const uint4*>(a);
-                const uint4* b4 = reinterpret_cast<const uint4*>(b);
-                uint4 xa[16], xb[16];
-#pragma unroll
-                for (int it = 0; it < 16; ++it) { xa[it] = a4[it * kWave + lane]; xb[it] = b4[it * kWave + lane]; }
-#pragma unroll
-                for (int it = 0; it < 16; ++it) {
-                    hist_add_word(col, max_u8x4(xa[it].x, xb[it].x));
-                    hist_add_word(col, max_u8x4(xa[it].y, xb[it].y));
-                    hist_add_word(col, max_u8x4(xa[it].z, xb[it].z));
-                    hist_add_word(col, max_u8x4(xa[it].w, xb[it].w));
-                }
-            } else if (nreg >= 1024) {
-                const uint4* a4 = reinterpret_cast<const uint4*>(a);
-                const uint4* b4 = reinterpret_cast<const uint4*>(b);
-                const int iters = (int)(nreg / (16 * kWave));
-                for (int it = 0; it < iters; ++it) {
-                    uint4 x = a4[it * kWave + lane], y = b4[it * kWave + lane];
-                    hist_add_word(col, max_u8x4(x.x, y.x));
-                    hist_add_word(col, max_u8x4(x.y, y.y));
-                    hist_add_word(col, max_u8x4(x.z, y.z));
-                    hist_add_word(col, max_u8x4(x.w, y.w));
-                }
-            } else {
-                for (long long t = lane; t < nreg; t += kWave) {
-                    uint32_t x = a[t], y = b[t];
-                    uint32_t v = (x > y ? x : y) & 63u;
-                    __hip_atomic_fetch_add(col + v * kWave, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                }
-            }
-        }
-        __syncthreads();
-        if (active) {
-            // lane l sums bin l over the 64 lane-columns, rotated so that lanes hit distinct banks
-            uint32_t s = 0;
-            const uint32_t* rowp = my + lane * kWave;
-#pragma unroll 8
-            for (int t = 0; t < kWave; ++t) s += rowp[(t + lane) & (kWave - 1)];
-            counts[j * 64 + lane] = s;
-        }
-        __syncthreads();
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
-// ertl_select_kernel: one LANE per histogram.  The 64 histograms of a wave are staged in LDS
-// (pitch 65 -> conflict-free) because the estimator indexes them with run-time k.
-//   MODE 0: est[j] = estimate                                     (selhip_ertl_estimate, cards)
-//   MODE 1: t = estimate; J = ((double)e_x + (double)e_y - t)/t; if (J >= tau) append   (selection.cpp:286-288)
-//   MODE 2: like 1 but writes selhip_result_t{x,y,(float)J} (drop-in launchers)
-// ---------------------------------------------------------------------------------------------
-struct LdsCounts {
-    const uint32_t* base;       // &lds[lane]
-    __device__ __forceinline__ uint32_t operator[](int k) const { return base[k * 65]; }
-};
-
-template <bool FMA, int MODE>
-__global__ __launch_bounds__(kWave)
-void ertl_select_kernel(const uint32_t* __restrict__ counts, const u64* __restrict__ n_dev, u64 n_host, u64 cap,
-                        int p, double relerr_scaled,
-                        double* __restrict__ est,
-                        const selhip_int2_t* __restrict__ pairs, const u64* __restrict__ ecard, double tau,
-                        selhip_pair_t* __restrict__ results, u64 results_cap, PassCounters* __restrict__ pc,
-                        selhip_result_t* __restrict__ results_f32, int* __restrict__ out_count_i32,
-                        u64 chunk_off, u64 chunk_len) {
-    __shared__ uint32_t lds[64 * 65];
-    const int lane = threadIdx.x;
-    u64 n = n_dev ? *n_dev : n_host;
-    if (n > cap) n = cap;
-    n = n > chunk_off ? min(n - chunk_off, chunk_len) : 0;       // window of the list; counts indexed from its start
-    if (pairs) pairs += chunk_off;
-    if (est) est += chunk_off;
-    for (u64 base = (u64)blockIdx.x * kWave; base < n; base += (u64)gridDim.x * kWave) {
-        __syncthreads();
-        // row r of the tile = histogram base+r; lane = bin -> coalesced 256 B reads
-        for (int r = 0; r < kWave; ++r) {
-            u64 j = base + r;
-            uint32_t v = (j < n) ? counts[j * 64 + lane] : (lane == 0 ? (1u << p) : 0u);
-            lds[lane * 65 + r] = v;
-        }
-        __syncthreads();
-        const u64 j = base + lane;
-        LdsCounts c{lds + lane};
-        double t = selhip::ertl_ml_estimate<FMA>(c, (unsigned)p, (unsigned)(64 - p), relerr_scaled);
-        if (j < n) {
-            if constexpr (MODE == 0) {
-                est[j] = t;
-            } else {
-                const selhip_int2_t pr = pairs[j];
-                const double e1 = (double)ecard[pr.x], e2 = (double)ecard[pr.y];
-                const double jacc = (e1 + e2 - t) / t;                       // selection.cpp:287
-                if (jacc >= tau) {                                           // selection.cpp:288
-                    if constexpr (MODE == 1) {
-                        u64 idx = atomicAdd(&pc->n_results, 1ull);
-                        if (idx < results_cap) { results[idx].i = pr.x; results[idx].k = pr.y; results[idx].jaccard = jacc; }
-                    } else {
-                        int idx = atomicAdd(out_count_i32, 1);
-                        results_f32[idx].x = pr.x; results_f32[idx].y = pr.y; results_f32[idx].sim = (float)jacc;
-                    }
-                }
-            }
-        }
-    }
-}
-
-
-// ---------------------------------------------------------------------------------------------
-// Auxiliary-HLL criteria (src/selection.cpp:152-173 hll_a, :206-227 hll_an; criteria_sketch.hpp:22-64).
-// enum_pairs_kernel lists the (CB-pruned) pair space of the rows explicitly -- only used when hll_a / hll_an
-// is the FIRST criterion; in the two-stage form (BASELINE config 5) the cheap smh_a join runs first and the
-// auxiliary criterion sees its survivors only: the selected set is the intersection either way.
-// ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kBlock)
-void enum_pairs_kernel(int n, const int* __restrict__ hi, const PassCounters* __restrict__ pc_in,
-                       int row_begin, int row_end, int n_rows_grid,
-                       selhip_int2_t* __restrict__ out, u64 out_cap, PassCounters* __restrict__ pc) {
-    __shared__ selhip_int2_t app_lds[kWavesPerBlock * kAppendCap];
-    const int i = row_begin + (int)(blockIdx.x % n_rows_grid);
-    const int chunk = blockIdx.x / n_rows_grid;
-    if (i >= row_end) return;
-    const int lane = threadIdx.x & (kWave - 1);
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
-    const int kmin = max(i + 1, pc_in->z0);
-    const int k = kmin + chunk * kBlock + (int)threadIdx.x;
-    WaveAppender app;
-    app.init(app_lds, wave, out, out_cap, &pc->n_aux_in);
-    app.push(k <= hi[i] && k < n, i, k, lane);
-    app.flush(lane);
-}
-
-// aux_filter_kernel<FMA, CRIT>: one LANE per pair; counts = union histogram of the two AUXILIARY sketches.
-//   CRIT 1 (hll_a):  t_hat = (size_t)U;  t+ = t_hat / (1 + Z*sigma_p);  K+ = ((1+gamma)*e_k - t+)/t+ >= tau
-//   CRIT 2 (hll_an): J = ((double)(e_i+e_k) - U)/U;  C = min(1, (1+Z*sigma_p)*e_k/U) * (1+gamma) * S;  J + C >= tau
-// zs = (double)(float)(Z*sigma_p) and S (= zs for order_n = 1) are computed on the host in float/double exactly as
-// criteria_sketch.hpp:7-20,25-31,39-40 do.  FMA flavour: g++ fuses (1+gamma)*card_B - t_hat_mas (criteria_sketch.hpp:41).
-template <bool FMA, int CRIT>
-__global__ __launch_bounds__(kWave)
-void aux_filter_kernel(const uint32_t* __restrict__ counts, const selhip_int2_t* __restrict__ pairs,
-                       const u64* __restrict__ n_dev, u64 chunk_off, u64 chunk_len, u64 cap,
-                       int p_aux, double relerr_scaled, const u64* __restrict__ ecard, double tau,
-                       double zs, double S_sum,
-                       selhip_int2_t* __restrict__ out, u64 out_cap, u64* __restrict__ out_count) {
-    __shared__ uint32_t lds[64 * 65];
-    __shared__ selhip_int2_t app_lds[kAppendCap];
-    const int lane = threadIdx.x;
-    u64 total = *n_dev;
-    if (total > cap) total = cap;
-    const u64 n = total > chunk_off ? min(total - chunk_off, chunk_len) : 0;     // pairs of this chunk
-    WaveAppender app;
-    app.init(app_lds, 0, out, out_cap, out_count);
-    for (u64 base = (u64)blockIdx.x * kWave; base < n; base += (u64)gridDim.x * kWave) {
-        __syncthreads();
-        for (int r = 0; r < kWave; ++r) {
-            u64 j = base + r;
-            lds[lane * 65 + r] = (j < n) ? counts[j * 64 + lane] : (lane == 0 ? (1u << p_aux) : 0u);
-        }
-        __syncthreads();
-        const u64 j = base + lane;
-        LdsCounts c{lds + lane};
-        const double U = selhip::ertl_ml_estimate<FMA>(c, (unsigned)p_aux, (unsigned)(64 - p_aux), relerr_scaled);
-        bool sel = false;
-        selhip_int2_t pr{0, 0};
-        if (j < n) {
-            pr = pairs[chunk_off + j];
-            const u64 ea = ecard[pr.x], eb = ecard[pr.y];
-            const double gamma = (double)ea / (double)eb;                         // criteria_sketch.hpp:24,38
-            if constexpr (CRIT == 1) {
-                const double t_hat = (double)(u64)(long long)U;                   // size_t t_hat = union_size()  (:61)
-                const double t_mas = t_hat / (1.0 + zs);                          // :40
-                const double K = selhip::muladd<FMA>(1.0 + gamma, (double)eb, -t_mas) / t_mas;   // :41
-                sel = K >= tau;                                                   // :63
-            } else {
-                const double J = ((double)(ea + eb) - U) / U;                     // :55
-                const double candv = (1.0 + zs) * (double)eb / U;                 // :32
-                const double minimo = candv < 1.0 ? candv : 1.0;                  // std::min(1.0, .)
-                const double C = minimo * (1 + gamma) * S_sum;                    // :33
-                sel = (J + C) >= tau;                                             // :57
-            }
-        }
-        app.push(sel, pr.x, pr.y, lane);
-    }
-    app.flush(lane);
-}
-
-// ---------------------------------------------------------------------------------------------
-// explicit pair lists (drop-in launchers and test building blocks): one LANE per pair.
-//   flags[j] = pair passes [e_y != 0] [CB] smh_a ;  optionally compacts survivors.
-// ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kBlock)
-void pairlist_smh_kernel(const u64* __restrict__ aux, int m, int n_rows, int n_bands,
-                         const selhip_int2_t* __restrict__ pairs, long long n_pairs,
-                         const double* __restrict__ cards, double tau, int check_cards, int use_cb,
-                         uint8_t* __restrict__ flags,
-                         selhip_int2_t* __restrict__ surv, u64 surv_cap, u64* __restrict__ surv_count) {
-    long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= n_pairs) return;
-    const selhip_int2_t pr = pairs[j];
-    bool ok = true;
-    if (check_cards) {
-        const u64 e1 = selhip::trunc_card(cards[pr.x]), e2 = selhip::trunc_card(cards[pr.y]);
-        if (e2 == 0) ok = false;                                             // selection.cpp:281
-        else if (use_cb && !cb_pred(tau, e1, e2)) ok = false;                // selection.cpp:282
-    }
-    if (ok) ok = smh_a_lane(aux + (long long)pr.x * m, aux + (long long)pr.y * m, n_rows, n_bands);
-    if (flags) flags[j] = ok ? 1 : 0;
-    if (ok && surv) {
-        u64 idx = atomicAdd(surv_count, 1ull);
-        if (idx < surv_cap) surv[idx] = pr;
-    }
-}
-
-__global__ __launch_bounds__(kBlock)
-void match_count_kernel(const u64* __restrict__ aux, int m, const selhip_int2_t* __restrict__ pairs,
-                        long long n_pairs, int32_t* __restrict__ matches) {
-    // one wave per pair: lanes stride the buckets, v_cmp_eq_u64 masks counted with s_bcnt1
-    const int lane = threadIdx.x & (kWave - 1);
-    long long j = ((long long)blockIdx.x * blockDim.x + threadIdx.x) / kWave;
-    if (j >= n_pairs) return;
-    const selhip_int2_t pr = pairs[j];
-    const u64* a = aux + (long long)pr.x * m;
-    const u64* b = aux + (long long)pr.y * m;
-    int cnt = 0;
-    for (int t0 = 0; t0 < m; t0 += kWave) {
-        int t = t0 + lane;
-        bool eq = (t < m) && (a[t] == b[t]);
-        cnt += __popcll(__ballot(eq));
-    }
-    if (lane == 0) matches[j] = cnt;
-}
-
-__global__ void truncate_cards_kernel(const double* __restrict__ cards, int n, u64* __restrict__ ecard) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) ecard[i] = selhip::trunc_card(cards[i]);
-}
-
-__global__ void iota_pairs_kernel(selhip_int2_t* pairs, int n) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) { pairs[i].x = i; pairs[i].y = i; }
-}
-
-// ---------------------------------------------------------------------------------------------
-// synth_kernel: one block per genome; registers / buckets are built in LDS with ds_max / ds_min.
-// ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kBlock)
-void synth_kernel(selhip::SynthParams sp, long long g_begin, long long g_end,
-                  uint8_t* __restrict__ hll, u64* __restrict__ aux, uint8_t* __restrict__ aux_hll) {
-    extern __shared__ unsigned char smem_raw[];
-    // layout: u64 smh[m] | u32 regs[16384] | u32 aregs[1<<p_aux]
-    u64* smh = reinterpret_cast<u64*>(smem_raw);
-    uint32_t* regs = reinterpret_cast<uint32_t*>(smem_raw + (size_t)sp.m * 8);
-    uint32_t* aregs = regs + 16384;
-    const int n_aux = sp.p_aux > 0 ? (1 << sp.p_aux) : 0;
-
-    const long long g = g_begin + blockIdx.x;
-    if (g >= g_end) return;
-    for (int t = threadIdx.x; t < sp.m; t += kBlock) smh[t] = ~0ull;
-    for (int t = threadIdx.x; t < 16384; t += kBlock) regs[t] = 0;
-    for (int t = threadIdx.x; t < n_aux; t += kBlock) aregs[t] = 0;
-    __syncthreads();
-
-    const uint32_t cluster = (uint32_t)(g / sp.cluster_size);
-    const uint32_t n_sh = selhip::synth_n_shared(sp, cluster);
-    const uint32_t n_pr = selhip::synth_n_private(sp, (uint32_t)g, n_sh);
-    for (int part = 0; part < 2; ++part) {
-        const uint32_t cnt = part == 0 ? n_sh : n_pr;
-        const u64 stream = part == 0 ? 2ull * cluster : 2ull * (u64)g + 1;
-        for (uint32_t e = threadIdx.x; e < cnt; e += kBlock) {
-            const u64 h = selhip::synth_element(sp, stream, e);
-            uint32_t idx, rank;
-            selhip::synth_hll_slot(h, 14, &idx, &rank);
-            atomicMax(&regs[idx], rank);
-            if (n_aux) {
-                selhip::synth_hll_slot(h, sp.p_aux, &idx, &rank);
-                atomicMax(&aregs[idx], rank);
-            }
-            uint32_t bucket; uint64_t value;
-            selhip::synth_smh_slot(h, sp.m, &bucket, &value);
-            atomicMin(&smh[bucket], (u64)value);
-        }
-    }
-    __syncthreads();
-    const long long r = g - g_begin;
-    for (int t = threadIdx.x; t < sp.m; t += kBlock) aux[r * sp.m + t] = smh[t];
-    uint32_t* out32 = reinterpret_cast<uint32_t*>(hll + r * 16384);
-    for (int t = threadIdx.x; t < 16384 / 4; t += kBlock)
-        out32[t] = regs[4 * t] | (regs[4 * t + 1] << 8) | (regs[4 * t + 2] << 16) | (regs[4 * t + 3] << 24);
-    if (n_aux && aux_hll)
-        for (int t = threadIdx.x; t < n_aux; t += kBlock) aux_hll[r * n_aux + t] = (uint8_t)aregs[t];
-}
-
-
-// =============================================================================================
-// Sketch construction on the GPU (reference: src/build_sketch.cpp:26-151).
-//   input : per genome, its FASTA records as one byte per base: 0..3 = A,C,G,T (either case), 4 = anything that
-//           resets the k-mer window (non-ACGT character, record boundary)        (build_sketch.cpp:68-84)
-//   output: HLL p=14 registers (hll.h:886-904 add/addh with WangHash, hash.h:42-53), auxiliary HLL p_aux registers,
-//           SuperMinHash h_[m] (bbmh.h:639-670)
-// SuperMinHash in parallel.  The reference's addh is sequential per sketch, but its RESULT is order-free: for an
-// element e the draws (k_j, r_j) come from a generator seeded with e alone, step j swaps p[k_j] <-> p[j] in a
-// permutation that starts as the identity for every element, and bucket p[j] is offered the value (j << 32) | r_j;
-// h[bucket] keeps the minimum.  The running bound a_ (largest integer part still present) only SKIPS offers that
-// cannot win.  Hence h = min over all elements and all steps j <= a_final, and it is computed here as
-//   pass 0: every k-mer in parallel offers its step-0 value (bucket k_0) with a 64-bit LDS atomic min;
-//   while a = max_b min(m-1, h[b] >> 32) exceeds the number of steps J offered so far: J = a and every k-mer re-runs
-//   its own chain up to step J (a handful of entries of p, kept in a tiny per-thread map) -- or, when a is large
-//   (few k-mers per bucket: tiny inputs), ONE lane runs the reference's sequential algorithm literally.
-// Either way the bytes equal the reference's (tests/test_build_sketch.py: 128 reference-written files).
-// ---------------------------------------------------------------------------------------------
-__host__ __device__ __forceinline__ u64 canonical_kmer(u64 kmer, unsigned k) {           // build_sketch.cpp:26-39
-    const u64 b_kmer = kmer;
-    kmer = ((kmer >> 2) & 0x3333333333333333ull) | ((kmer & 0x3333333333333333ull) << 2);
-    kmer = ((kmer >> 4) & 0x0F0F0F0F0F0F0F0Full) | ((kmer & 0x0F0F0F0F0F0F0F0Full) << 4);
-    kmer = ((kmer >> 8) & 0x00FF00FF00FF00FFull) | ((kmer & 0x00FF00FF00FF00FFull) << 8);
-    kmer = ((kmer >> 16) & 0x0000FFFF0000FFFFull) | ((kmer & 0x0000FFFF0000FFFFull) << 16);
-    kmer = (kmer >> 32) | (kmer << 32);
-    const u64 reverse = (~0ull - kmer) >> (64 - (k << 1));
-    return b_kmer < reverse ? b_kmer : reverse;
-}
-__host__ __device__ __forceinline__ u64 wang_hash(u64 key) {                              // hash.h:42-53
-    key = (~key) + (key << 21);
-    key = key ^ (key >> 24);
-    key = (key + (key << 3)) + (key << 8);
-    key = key ^ (key >> 14);
-    key = (key + (key << 2)) + (key << 4);
-    key = key ^ (key >> 28);
-    key = key + (key << 31);
-    return key;
-}
-__device__ __forceinline__ u64 wyhash64_next(u64& state) {                               // aesctr/wy.h:44-59
-    state += 0x60bee2bee120fc15ull;
-    const u64 x = state ^ 0xe7037ed1a0b428dbull, y = state;
-    return (x * y) ^ __umul64hi(x, y);
-}
-__device__ __forceinline__ void hll_slot(u64 h, int p, uint32_t* idx, uint32_t* rank) {   // hll.h:886-888
-    *idx = (uint32_t)(h >> (64 - p));
-    *rank = (uint32_t)__clzll((long long)(((h << 1) | 1) << (p - 1))) + 1;
-}
-
-// k-mer ending at position i of the genome (codes[0..L)); false if the window holds a reset code
-__device__ __forceinline__ bool kmer_at(const uint8_t* __restrict__ codes, long long i, int k, u64* out) {
-    u64 kmer = 0;
-    bool ok = true;
-    for (int t = 0; t < k; ++t) {
-        const uint32_t c = codes[i - (k - 1) + t];
-        ok = ok && (c < 4);
-        kmer = (kmer << 2) | (c & 3);
-    }
-    *out = kmer;
-    return ok;
-}
-
-// byte-wide HLL registers packed four to an LDS word: max via read-check + CAS (updates become rare once the
-// registers have warmed up, so the CAS loop almost never runs)
-__device__ __forceinline__ void lds_byte_max(uint32_t* words, uint32_t idx, uint32_t rank) {
-    uint32_t* w = words + (idx >> 2);
-    const int sh = (idx & 3) * 8;
-    uint32_t cur = *(volatile uint32_t*)w;
-    while (((cur >> sh) & 0xFFu) < rank) {
-        const uint32_t want = (cur & ~(0xFFu << sh)) | (rank << sh);
-        const uint32_t prev = atomicCAS(w, cur, want);
-        if (prev == cur) break;
-        cur = prev;
-    }
-}
-
-constexpr int kSketchJmaxParallel = 15;
-constexpr int kSketchSeg = 64;          // consecutive k-mer end positions rolled by one thread
-
-// visits every valid k-mer of the genome once: thread t owns segments t, t+256, ... of kSketchSeg end positions and
-// rolls the 2-bit window through them (30 warm-up bases per segment)
-template <typename F>
-__device__ __forceinline__ void for_each_kmer(const uint8_t* __restrict__ codes, long long L, int k, F&& f) {
-    const u64 kmask = k == 32 ? ~0ull : ((1ull << (2 * k)) - 1);
-    for (long long seg = (long long)(k - 1) + (long long)threadIdx.x * kSketchSeg; seg < L; seg += (long long)kBlock * kSketchSeg) {
-        const long long end = min(seg + kSketchSeg, L);
-        u64 kmer = 0;
-        int bases = 0;                                       // valid bases in the window, capped at k
-        for (long long i = seg - (k - 1); i < end; ++i) {
-            const uint32_t c = codes[i];
-            if (c < 4) { kmer = ((kmer << 2) | c) & kmask; bases = min(bases + 1, k); }
-            else       { kmer = 0; bases = 0; }                                       // build_sketch.cpp:83
-            if (i >= seg && bases == k) f(kmer);
-        }
-    }
-}
-
-__global__ __launch_bounds__(kBlock)
-void sketch_build_kernel(const uint8_t* __restrict__ codes_all, const long long* __restrict__ offsets, int k,
-                         int m, int p_aux, uint8_t* __restrict__ hll_out, u64* __restrict__ smh_out,
-                         uint8_t* __restrict__ aux_out) {
-    extern __shared__ unsigned char smem_raw[];
-    // layout: u64 h[m] | u32 regs[16384/4] (byte registers) | u32 aregs[(1<<p_aux)/4] | u32 p[m] | u32 q[m] | i32 b[m] | i32 ctl[4]
-    const int n_aux = (aux_out && p_aux > 0) ? (1 << p_aux) : 0;
-    const int ms = smh_out ? m : 0;
-    u64* h = reinterpret_cast<u64*>(smem_raw);
-    uint32_t* regs = reinterpret_cast<uint32_t*>(smem_raw + (size_t)ms * 8);
-    uint32_t* aregs = regs + 16384 / 4;
-    uint32_t* pp = aregs + (n_aux + 3) / 4;
-    uint32_t* qq = pp + ms;
-    int* bb = reinterpret_cast<int*>(qq + ms);
-    int* ctl = bb + ms;
-
-    const long long g = blockIdx.x;
-    const uint8_t* codes = codes_all + offsets[g];
-    const long long L = offsets[g + 1] - offsets[g];
-    const uint32_t mask = (uint32_t)(m - 1);
-
-    for (int t = threadIdx.x; t < ms; t += kBlock) h[t] = ~0ull;
-    for (int t = threadIdx.x; t < 16384 / 4; t += kBlock) regs[t] = 0;
-    for (int t = threadIdx.x; t < (n_aux + 3) / 4; t += kBlock) aregs[t] = 0;
-    if (threadIdx.x == 0) ctl[0] = 0;
-    __syncthreads();
-
-    // pass 0: HLL registers and the step-0 offer of every k-mer
-    for_each_kmer(codes, L, k, [&](u64 kmer) {
-        const u64 canon = canonical_kmer(kmer, (unsigned)k);
-        const u64 hv = wang_hash(canon);                                              // hll.h:901-904 addh
-        uint32_t idx, rank;
-        hll_slot(hv, 14, &idx, &rank);
-        lds_byte_max(regs, idx, rank);
-        if (n_aux) { hll_slot(hv, p_aux, &idx, &rank); lds_byte_max(aregs, idx, rank); }
-        if (ms) {
-            u64 st = canon ? canon : 1337ull;                                         // WyRand(seed ? seed : 1337)
-            const u64 v = wyhash64_next(st);
-            const u64 offer = v >> 32;                                                // j = 0: value (0<<32)|r_0
-            u64* slot = &h[(uint32_t)v & mask];                                       //        bucket k_0
-            if (offer < *(volatile u64*)slot) atomicMin(slot, offer);
-        }
-    });
-    __syncthreads();
-
-    if (ms) {
-        int J = 0;
-        while (true) {
-            // a = max_b min(m-1, h[b] >> 32)    (bbmh.h:657-664: b_ / a_ bookkeeping, stated directly)
-            int la = 0;
-            for (int t = threadIdx.x; t < ms; t += kBlock) la = max(la, (int)min((u64)(m - 1), h[t] >> 32));
-            atomicMax(&ctl[0], la);
-            __syncthreads();
-            const int a = ctl[0];
-            __syncthreads();
-            if (threadIdx.x == 0) ctl[0] = 0;
-            if (a <= J) break;
-            if (a > kSketchJmaxParallel) {
-                // few k-mers per bucket: run the reference's sequential algorithm literally on one lane
-                for (int t = threadIdx.x; t < ms; t += kBlock) { h[t] = ~0ull; qq[t] = 0xFFFFFFFFu; pp[t] = 0; bb[t] = 0; }
-                __syncthreads();
-                if (threadIdx.x == 0) {
-                    bb[m - 1] = m;                                                    // bbmh.h:575
-                    u64 aa = (u64)(m - 1), ii = 0;
-                    for (long long i = k - 1; i < L; ++i) {
-                        u64 kmer;
-                        if (!kmer_at(codes, i, k, &kmer)) continue;
-                        const u64 canon = canonical_kmer(kmer, (unsigned)k);
-                        u64 st = canon ? canon : 1337ull;
-                        u64 j = 0;
-                        while (j <= aa) {                                             // bbmh.h:643-668
-                            const u64 v = wyhash64_next(st);
-                            const uint32_t kk = (uint32_t)v & mask;
-                            if ((u64)qq[j] != ii) { qq[j] = (uint32_t)ii; pp[j] = (uint32_t)j; }
-                            if ((u64)qq[kk] != ii) { qq[kk] = (uint32_t)ii; pp[kk] = kk; }
-                            const uint32_t tmp = pp[kk]; pp[kk] = pp[j]; pp[j] = tmp;
-                            const u64 crj = (j << 32) | (v >> 32);
-                            if (crj < h[pp[j]]) {
-                                const uint32_t jprime = min((uint32_t)(m - 1), (uint32_t)(h[pp[j]] >> 32));
-                                h[pp[j]] = crj;
-                                if (j < jprime) {
-                                    --bb[jprime];
-                                    ++bb[j];
-                                    while (bb[aa] == 0) --aa;
-                                }
-                            }
-                            ++j;
-                        }
-                        ++ii;
-                    }
-                }
-                __syncthreads();
-                break;
-            }
-            J = a;
-            // every k-mer re-runs its chain up to step J; only steps >= 1 can be new (atomic min is idempotent)
-            for_each_kmer(codes, L, k, [&](u64 kmer) {
-                const u64 canon = canonical_kmer(kmer, (unsigned)k);
-                u64 st = canon ? canon : 1337ull;
-                uint32_t pos[2 * (kSketchJmaxParallel + 1)], val[2 * (kSketchJmaxParallel + 1)];
-                int cnt = 0;
-                for (int j = 0; j <= J; ++j) {
-                    const u64 v = wyhash64_next(st);
-                    const uint32_t kk = (uint32_t)v & mask;
-                    uint32_t pj = (uint32_t)j, pk = kk;
-                    int ij = -1, ik = -1;
-                    for (int t = 0; t < cnt; ++t) {
-                        if (pos[t] == (uint32_t)j) { pj = val[t]; ij = t; }
-                        if (pos[t] == kk) { pk = val[t]; ik = t; }
-                    }
-                    // swap(p[kk], p[j])
-                    if (ik >= 0) val[ik] = pj; else { pos[cnt] = kk; val[cnt] = pj; ik = cnt++; }
-                    if (kk != (uint32_t)j) {
-                        if (ij >= 0) val[ij] = pk; else { pos[cnt] = (uint32_t)j; val[cnt] = pk; cnt++; }
-                    }
-                    const uint32_t bucket = (kk == (uint32_t)j) ? pj : pk;            // p[j] after the swap
-                    atomicMin(&h[bucket], ((u64)j << 32) | (v >> 32));
-                }
-            });
-            __syncthreads();
-        }
-    }
-    __syncthreads();
-    uint32_t* out32 = reinterpret_cast<uint32_t*>(hll_out + g * 16384);
-    for (int t = threadIdx.x; t < 16384 / 4; t += kBlock) out32[t] = regs[t];
-    for (int t = threadIdx.x; t < n_aux; t += kBlock) aux_out[g * n_aux + t] = (uint8_t)(aregs[t >> 2] >> ((t & 3) * 8));
-    for (int t = threadIdx.x; t < ms; t += kBlock) smh_out[g * (long long)m + t] = h[t];
-}
-
-__global__ __launch_bounds__(kBlock)
-void permute_rows_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst, const int32_t* __restrict__ perm,
-                         long long n_rows, long long row_vec) {
-    // one block per destination row (grid-stride), 16 B per lane
-    for (long long r = blockIdx.x; r < n_rows; r += gridDim.x) {
-        const uint4* s = src + (long long)perm[r] * row_vec;
-        uint4* d = dst + r * row_vec;
-        for (long long t = threadIdx.x; t < row_vec; t += kBlock) d[t] = s[t];
-    }
-}
-
-__global__ void permute_bytes_kernel(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst,
-                                     const int32_t* __restrict__ perm, long long n_rows, long long row_bytes) {
-    for (long long r = blockIdx.x; r < n_rows; r += gridDim.x) {
-        const uint8_t* s = src + (long long)perm[r] * row_bytes;
-        uint8_t* d = dst + r * row_bytes;
-        for (long long t = threadIdx.x; t < row_bytes; t += blockDim.x) d[t] = s[t];
-    }
-}
 
 // =============================================================================================
 // host side
@@ -1426,9 +389,6 @@ int enqueue_pass(selhip_ctx* c) {
     HIPCHK(&c->err, hipMemsetAsync(c->pc.p, 0, sizeof(PassCounters), c->stream));
     {
         TimerScope t(c, T_PREP);
-        // z0 defaults to n ("no genome with e != 0"): written before the kernel
-        int z0_init = n;
-        HIPCHK(&c->err, hipMemcpyAsync(&c->pc.p->z0, &z0_init, sizeof(int), hipMemcpyHostToDevice, c->stream));
         hipLaunchKernelGGL(cb_bounds_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream,
                            c->d_cards, n, tau, c->mode == SELHIP_MODE_CB_SMH ? 1 : 0, rb, re, c->ecard.p, c->hi.p, c->pc.p);
         HIPCHK(&c->err, hipGetLastError());
@@ -1820,6 +780,19 @@ int selhip_ctx_copy_results(selhip_ctx* c, selhip_pair_t* d_dst, int64_t cap) {
         HIPCHK(&c->err, hipMemcpyAsync(d_dst, c->results.p, (size_t)cnt * sizeof(selhip_pair_t), hipMemcpyDeviceToDevice, c->stream));
     }
     return SELHIP_OK;
+}
+
+int selhip_ctx_copy_results_framed(selhip_ctx* c, void* d_dst, int64_t cap_records) {
+    // frame = one 16-byte header record {u64 count, u64 0} followed by the records; both copies are device-to-device
+    if (!c || !d_dst || cap_records < 0) return SELHIP_E_BADARG;
+    if (!c->have_run) return SELHIP_E_STATE;
+    HIPCHK(&c->err, hipSetDevice(c->device));
+    HIPCHK(&c->err, hipMemcpyAsync(d_dst, &c->pc.p->n_results, sizeof(u64), hipMemcpyDeviceToDevice, c->stream));
+    const int64_t cnt = std::min<int64_t>((int64_t)c->last.n_results, cap_records);
+    if (cnt > 0)
+        HIPCHK(&c->err, hipMemcpyAsync((char*)d_dst + sizeof(selhip_pair_t), c->results.p, (size_t)cnt * sizeof(selhip_pair_t),
+                                       hipMemcpyDeviceToDevice, c->stream));
+    return (int64_t)c->last.n_results > cap_records ? SELHIP_E_OVERFLOW : SELHIP_OK;
 }
 
 int selhip_ctx_timing(selhip_ctx* c, int enable) {

@@ -202,6 +202,14 @@ class Selector:
         check(self._lib.selhip_ctx_copy_results(self._ctx, tensor.data_ptr(), cap), self._ctx)
         return min(cap, self.result_count())
 
+    def copy_results_framed(self, tensor) -> int:
+        """D2D: tensor[0] (16 B) = {count, 0}, records from tensor[1:]; returns the (host-known) count"""
+        cap = tensor.numel() * tensor.element_size() // PAIR_DTYPE.itemsize - 1
+        rc = self._lib.selhip_ctx_copy_results_framed(self._ctx, tensor.data_ptr(), cap)
+        if rc not in (0, -3):
+            check(rc, self._ctx)
+        return self.result_count()
+
     def stats(self) -> dict:
         st = (C.c_int64 * 4)()
         check(self._lib.selhip_ctx_stats(self._ctx, st), self._ctx)

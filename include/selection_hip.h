@@ -160,6 +160,9 @@ int selhip_ctx_result_device(selhip_ctx* ctx, const selhip_pair_t** d_results, i
 /* device-to-device copy of min(count, cap) unsorted records into caller memory (e.g. a torch tensor that
  * is then handed to an RCCL collective); asynchronous on the context's stream. */
 int selhip_ctx_copy_results(selhip_ctx* ctx, selhip_pair_t* d_dst, int64_t cap);
+/* same, framed for a fixed-size collective: d_dst[0] = 16-byte header {u64 count, u64 0}, records from d_dst + 16;
+ * d_dst must hold cap_records + 1 records.  Returns SELHIP_E_OVERFLOW (after copying cap_records) if count > cap. */
+int selhip_ctx_copy_results_framed(selhip_ctx* ctx, void* d_dst, int64_t cap_records);
 
 /* average device time (ms, HIP events on the context's stream) of the named kernel over the launches
  * since the last reset; names: "stage1", "hist", "select", "prep", "total".  <0 if never launched. */
