@@ -41,6 +41,7 @@ def parse():
     ap.add_argument("--mode", choices=["smh_a", "CB+smh_a"], default="smh_a")
     ap.add_argument("--algo", choices=["auto", "stream", "sig"], default="auto")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--pipeline", type=int, default=-1, help="-1 auto, 0 off, 2..8 row chunks (stage 1 of chunk c+1 overlaps stage 2 of chunk c)")
     ap.add_argument("--pcie", action="store_true", help="also time a PCIe-inclusive pass (host buffers -> upload -> run)")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
                     help="gloo = rehearsal of the multi-rank logic on a box with fewer GPUs than ranks (records staged through the host)")
@@ -92,6 +93,7 @@ def main():
     cards = cards_t.cpu().numpy()
     sel = pkg.Selector(local_rank)
     sel.attach(hll_t, aux_t, cards_t)
+    sel.set_pipeline(args.pipeline)
     two_stage = cfg.p_aux > 0                      # BASELINE configs[4]: hll_a prefilter + smh_a
     if two_stage:
         sel.attach_aux_hll(aux_hll_t, cfg.p_aux)
@@ -196,7 +198,11 @@ def main():
         used_sig = sel.kernel_ms("join") > 0
         pairs_rank0 = st["evaluated"]
         alg_bytes = pairs_rank0 * 8 * cfg.m                     # 8*m bytes per pair-comparison
-        dom_ms = sel.kernel_ms("join") if used_sig else stage1_ms
+        dom_key = "join" if used_sig else "stage1"
+        dom_pass_ms = sel.kernel_ms(dom_key)                     # all launches of one pass (a pipelined pass: one per row chunk)
+        launches = max(1.0, sel.kernel_launches(dom_key))
+        dom_ms = dom_pass_ms / launches                          # average launch duration
+        alg_bytes = alg_bytes / launches                         # algorithmic bytes of one launch
         dom_name = f"sig_join_kernel<{n_bands}>" if used_sig else "smh_stream_kernel"
         achieved = alg_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else None
         traffic = None
@@ -204,6 +210,7 @@ def main():
         if tfile.exists():
             try:
                 traffic = json.loads(tfile.read_text()).get(f"{args.workload}:{'sig' if used_sig else 'stream'}")
+                traffic = traffic / launches if traffic else traffic        # stored per step
             except Exception:
                 traffic = None
         hist_ms = sel.kernel_ms("hist")
@@ -224,14 +231,14 @@ def main():
             "bucket_pair_comparisons_per_s": value * cfg.m,
             "roofline": {"bound": "hbm", "kernel": dom_name + " (stage 1, all-pairs)", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
-                         "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": dom_ms,
+                         "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": dom_ms, "launches_per_step": launches,
                          "note": "algorithmic bytes = 8*m per pair-comparison (SURVEY.md 8d: one candidate sketch streamed per "
                                  "pair, query on chip). Both stage-1 kernels reuse every byte they load across a tile of "
                                  "queries, so the algorithmic rate exceeds the HBM peak; `traffic` = measured HBM bytes/launch "
                                  "(rocprofv3 FETCH_SIZE/WRITE_SIZE, profiles/). The signature join is bound by VALU issue "
                                  "(1.5 VALU per band and 64 pairs), see `valu`."},
             "stage2_roofline": {"bound": "hbm", "kernel": "hll_union_hist_kernel", "achieved": (surv0 * 32768 / (hist_ms * 1e-3) / 1e9) if hist_ms > 0 else None,
-                                "peak": HBM_PEAK_GBS, "unit": "GB/s", "avg_launch_ms": hist_ms, "algorithmic_bytes_per_launch": surv0 * 32768,
+                                "peak": HBM_PEAK_GBS, "unit": "GB/s", "ms_per_step": hist_ms, "algorithmic_bytes_per_step": surv0 * 32768,
                                 "note": "2 x 16 KiB of HLL registers per surviving pair"},
             "kernel_ms": kernels,
         }
@@ -239,6 +246,7 @@ def main():
             groups = (n_genomes + 63) // 64
             wave_queries = pairs_rank0 / 64.0                    # one query against one 64-candidate group
             valu = wave_queries * n_bands * 1.5
+            dom_ms = dom_pass_ms
             out["roofline"]["valu"] = {"achieved_wave_instr_per_s": valu / (dom_ms * 1e-3), "peak_wave_instr_per_s": 256 * 4 * 2.4e9 / 4,
                                        "frac": valu / (dom_ms * 1e-3) / (256 * 4 * 2.4e9 / 4),
                                        "note": "peak = 1024 SIMDs x 2.4 GHz / 4 cycles per wave64 VALU instruction"}

@@ -57,6 +57,7 @@ HIP_SYMBOLS = {
     "selhip_last_error": (_cp, [_vp]),
     "selhip_ctx_set_stream": (_i, [_vp, _vp]),
     "selhip_ctx_set_fp_mode": (_i, [_vp, _i]),
+    "selhip_ctx_set_pipeline": (_i, [_vp, _i]),
     "selhip_ctx_upload": (_i, [_vp, _vp, _vp, _vp, _i64, _i, _i]),
     "selhip_ctx_attach": (_i, [_vp, _vp, _vp, _vp, _i64, _i, _i]),
     "selhip_ctx_upload_aux_hll": (_i, [_vp, _vp, _i]),
@@ -74,6 +75,7 @@ HIP_SYMBOLS = {
     "selhip_ctx_copy_results": (_i, [_vp, _vp, _i64]),
     "selhip_ctx_copy_results_framed": (_i, [_vp, _vp, _i64]),
     "selhip_ctx_kernel_ms": (_d, [_vp, _cp]),
+    "selhip_ctx_kernel_launches": (_d, [_vp, _cp]),
     "selhip_ctx_timing": (_i, [_vp, _i]),
     "selhip_smh_a_pairs": (_i, [_vp, _i, _i, _i, _vp, _i64, _vp, _vp]),
     "selhip_hll_union_hist": (_i, [_vp, _i, _vp, _i64, _vp, _vp]),

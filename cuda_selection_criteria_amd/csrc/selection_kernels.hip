@@ -87,6 +87,8 @@ struct KernelTimer {
     long launches = 0;
 };
 
+constexpr int kMaxChunks = 8;
+
 enum { T_PREP = 0, T_STAGE1, T_HIST, T_SELECT, T_TOTAL, T_SIGBUILD, T_JOIN, T_VERIFY, T_AUX, T_COUNT };
 const char* kTimerNames[T_COUNT] = {"prep", "stage1", "hist", "select", "total", "sigbuild", "join", "verify", "aux"};
 
@@ -124,7 +126,12 @@ struct selhip_ctx {
     int p_aux = 0;
     int criterion = 0;
     DevBuf<uint32_t> sigQ, sigT;        // ALGO_SIG: band signatures, query-major / band-major
-    PassCounters* h_pc = nullptr;       // pinned host mirror
+    PassCounters* h_pc = nullptr;       // pinned host mirror of the kMaxChunks + 1 counter blocks
+    // stage pipeline: stage 1 of row chunk c+1 (VALU-bound) overlaps stage 2 of chunk c (memory/LDS-bound)
+    hipStream_t st_stage1 = nullptr, st_stage2 = nullptr;     // internal non-blocking streams
+    hipEvent_t ev_start = nullptr, ev_end = nullptr, ev_chunk[8] = {};
+    int n_chunks_last = 1;
+    int pipeline = -1;                  // -1 auto, 0 off, >0 forced chunk count
 
     // last run parameters (for overflow re-runs)
     bool have_run = false, pending = false;
@@ -150,19 +157,30 @@ int check_device(std::string* err) {
 }
 
 struct TimerScope {
-    selhip_ctx* c; int id; hipEvent_t a = nullptr, b = nullptr;
-    TimerScope(selhip_ctx* c_, int id_) : c(c_), id(id_) {
+    selhip_ctx* c; int id; hipStream_t st; hipEvent_t a = nullptr, b = nullptr;
+    TimerScope(selhip_ctx* c_, int id_) : TimerScope(c_, id_, c_->stream) {}
+    TimerScope(selhip_ctx* c_, int id_, hipStream_t st_) : c(c_), id(id_), st(st_) {
         if (c->timing) {
             (void)hipEventCreate(&a); (void)hipEventCreate(&b);
-            (void)hipEventRecord(a, c->stream);
+            (void)hipEventRecord(a, st);
         }
     }
     ~TimerScope() {
         if (c->timing) {
-            (void)hipEventRecord(b, c->stream);
+            (void)hipEventRecord(b, st);
             c->timers[id].ev.emplace_back(a, b);
         }
     }
+};
+
+// where one stage-1 launch (a chunk of query rows) writes: its stream, its slice of the candidate / survivor lists
+// and its own counter block; pc0 (the pass's block 0) carries what every chunk reads (z0) and the result counter
+struct StageIO {
+    hipStream_t st;
+    selhip_int2_t* cand;
+    selhip_int2_t* surv;
+    u64 cap;
+    PassCounters* pc;
 };
 
 void drain_timers(selhip_ctx* c) {
@@ -190,7 +208,7 @@ int ilog2(int x) { int l = 0; while ((1 << l) < x) ++l; return l; }
 
 // ---- stage-1 dispatch ------------------------------------------------------------------------
 template <int NCH, int LOG2R>
-hipError_t launch_stream(selhip_ctx* c, int r_rt, int row_begin, int row_end) {
+hipError_t launch_stream(selhip_ctx* c, const StageIO& io, int r_rt, int row_begin, int row_end) {
     constexpr int Q = kQueryVgprBudget / NCH;
     const int n = (int)c->n;
     const int n_tiles = (row_end - row_begin + Q - 1) / Q;
@@ -200,24 +218,24 @@ hipError_t launch_stream(selhip_ctx* c, int r_rt, int row_begin, int row_end) {
     if (n_tiles <= 0 || n_chunks <= 0) return hipSuccess;
     const long long blocks = (long long)n_tiles * n_chunks;
     if (blocks > 0x7FFFFFFFll) return hipErrorInvalidValue;
-    hipLaunchKernelGGL((smh_stream_kernel<NCH, LOG2R>), dim3((unsigned)blocks), dim3(kBlock), 0, c->stream,
+    hipLaunchKernelGGL((smh_stream_kernel<NCH, LOG2R>), dim3((unsigned)blocks), dim3(kBlock), 0, io.st,
                        reinterpret_cast<const u64x2*>(c->d_aux), n, r_rt, c->hi.p, c->pc.p,
-                       row_begin, row_end, n_tiles, chunk_base, c->surv.p, (u64)c->surv.cap, c->pc.p);
+                       row_begin, row_end, n_tiles, chunk_base, io.surv, io.cap, io.pc);
     return hipGetLastError();
 }
 
 template <int NCH>
-hipError_t launch_stream_r(selhip_ctx* c, int n_rows, int rb, int re) {
+hipError_t launch_stream_r(selhip_ctx* c, const StageIO& io, int n_rows, int rb, int re) {
     const int l = n_rows >= 128 ? 7 : ilog2(n_rows);
     switch (l) {
-        case 0: return launch_stream<NCH, 0>(c, n_rows, rb, re);
-        case 1: return launch_stream<NCH, 1>(c, n_rows, rb, re);
-        case 2: return launch_stream<NCH, 2>(c, n_rows, rb, re);
-        case 3: return launch_stream<NCH, 3>(c, n_rows, rb, re);
-        case 4: return launch_stream<NCH, 4>(c, n_rows, rb, re);
-        case 5: return launch_stream<NCH, 5>(c, n_rows, rb, re);
-        case 6: return launch_stream<NCH, 6>(c, n_rows, rb, re);
-        default: return launch_stream<NCH, 7>(c, n_rows, rb, re);
+        case 0: return launch_stream<NCH, 0>(c, io, n_rows, rb, re);
+        case 1: return launch_stream<NCH, 1>(c, io, n_rows, rb, re);
+        case 2: return launch_stream<NCH, 2>(c, io, n_rows, rb, re);
+        case 3: return launch_stream<NCH, 3>(c, io, n_rows, rb, re);
+        case 4: return launch_stream<NCH, 4>(c, io, n_rows, rb, re);
+        case 5: return launch_stream<NCH, 5>(c, io, n_rows, rb, re);
+        case 6: return launch_stream<NCH, 6>(c, io, n_rows, rb, re);
+        default: return launch_stream<NCH, 7>(c, io, n_rows, rb, re);
     }
 }
 
@@ -225,14 +243,14 @@ bool stream_supported(int m, int n_rows) {
     return is_pow2(m) && m >= 128 && m <= 2048 && is_pow2(n_rows) && n_rows <= m;
 }
 
-hipError_t launch_stage1(selhip_ctx* c, int n_rows, int n_bands, int rb, int re) {
+hipError_t launch_stage1(selhip_ctx* c, const StageIO& io, int n_rows, int n_bands, int rb, int re) {
     if (stream_supported(c->m, n_rows)) {
         switch (c->m / 128) {
-            case 1: return launch_stream_r<1>(c, n_rows, rb, re);
-            case 2: return launch_stream_r<2>(c, n_rows, rb, re);
-            case 4: return launch_stream_r<4>(c, n_rows, rb, re);
-            case 8: return launch_stream_r<8>(c, n_rows, rb, re);
-            case 16: return launch_stream_r<16>(c, n_rows, rb, re);
+            case 1: return launch_stream_r<1>(c, io, n_rows, rb, re);
+            case 2: return launch_stream_r<2>(c, io, n_rows, rb, re);
+            case 4: return launch_stream_r<4>(c, io, n_rows, rb, re);
+            case 8: return launch_stream_r<8>(c, io, n_rows, rb, re);
+            case 16: return launch_stream_r<16>(c, io, n_rows, rb, re);
         }
     }
     const int rows = re - rb;
@@ -241,9 +259,9 @@ hipError_t launch_stage1(selhip_ctx* c, int n_rows, int n_bands, int rb, int re)
     const long long blocks = (long long)rows * chunks;
     if (blocks <= 0) return hipSuccess;
     if (blocks > 0x7FFFFFFFll) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(smh_generic_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, c->stream,
+    hipLaunchKernelGGL(smh_generic_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, io.st,
                        c->d_aux, n, c->m, n_rows, n_bands, c->hi.p, c->pc.p, rb, re, rows,
-                       c->surv.p, (u64)c->surv.cap, c->pc.p);
+                       io.surv, io.cap, io.pc);
     return hipGetLastError();
 }
 
@@ -253,16 +271,10 @@ bool sig_supported(int m, int n_rows, int n_bands) {
     return is_pow2(n_rows) && (n_bands == 8 || n_bands == 16 || n_bands == 32 || n_bands == 64 || n_bands == 128);
 }
 
-int env_int(const char* name, int dflt) {
-    const char* v = std::getenv(name);
-    return v && *v ? std::atoi(v) : dflt;
-}
-
 template <int NB>
-hipError_t launch_join(selhip_ctx* c, int n_pad, int rb, int re) {
+hipError_t launch_join(selhip_ctx* c, const StageIO& io, int n_pad, int rb, int re) {
     const int n = (int)c->n;
-    int qt = std::max(16, env_int("SELHIP_JOIN_QT", 128));                            // development knob
-    qt = (qt + 15) / 16 * 16;
+    const int qt = 128;                 // query rows per block (multiple of 16); 32..128 measured equal, 256+ slower
     const int n_tiles = (re - rb + qt - 1) / qt;
     const int group_base = ((rb + 1) / kWave / kWavesPerBlock) * kWavesPerBlock;      // candidates k > row_begin
     const int n_groups = (n + kWave - 1) / kWave - group_base;
@@ -270,39 +282,42 @@ hipError_t launch_join(selhip_ctx* c, int n_pad, int rb, int re) {
     if (n_tiles <= 0 || n_gblocks <= 0) return hipSuccess;
     const long long blocks = (long long)n_tiles * n_gblocks;
     if (blocks > 0x7FFFFFFFll) return hipErrorInvalidValue;
-    hipLaunchKernelGGL((sig_join_kernel<NB>), dim3((unsigned)blocks), dim3(kBlock), 0, c->stream,
+    hipLaunchKernelGGL((sig_join_kernel<NB>), dim3((unsigned)blocks), dim3(kBlock), 0, io.st,
                        c->sigT.p, n, n_pad, c->hi.p, c->pc.p, rb, re, n_tiles, group_base, qt,
-                       c->cand.p, (u64)c->cand.cap, c->pc.p);
+                       io.cand, io.cap, io.pc);
     return hipGetLastError();
 }
 
-hipError_t launch_stage1_sig(selhip_ctx* c, int n_rows, int n_bands, int rb, int re) {
+hipError_t launch_sig_build(selhip_ctx* c, int n_rows, int n_bands) {
     const int n = (int)c->n;
     const int n_pad = ((n + kWave - 1) / kWave) * kWave;
-    {
-        TimerScope t(c, T_SIGBUILD);
-        const long long threads = n_rows <= kWave ? (long long)n * c->m : (long long)n * n_bands;
-        hipLaunchKernelGGL(sig_build_kernel, dim3((unsigned)((threads + kBlock - 1) / kBlock)), dim3(kBlock), 0, c->stream,
-                           c->d_aux, n, c->m, n_rows, n_bands, n_pad, c->sigQ.p, c->sigT.p);
-        hipError_t e = hipGetLastError();
-        if (e != hipSuccess) return e;
-    }
+    TimerScope t(c, T_SIGBUILD);
+    const long long threads = n_rows <= kWave ? (long long)n * c->m : (long long)n * n_bands;
+    hipLaunchKernelGGL(sig_build_kernel, dim3((unsigned)((threads + kBlock - 1) / kBlock)), dim3(kBlock), 0, c->stream,
+                       c->d_aux, n, c->m, n_rows, n_bands, n_pad, c->sigQ.p, c->sigT.p);
+    return hipGetLastError();
+}
+
+// signature join + exact verification of the query rows [rb, re) (sig_build must have run)
+hipError_t launch_stage1_sig(selhip_ctx* c, const StageIO& io, int n_rows, int n_bands, int rb, int re) {
+    const int n = (int)c->n;
+    const int n_pad = ((n + kWave - 1) / kWave) * kWave;
     hipError_t e = hipSuccess;
     {
-    TimerScope t(c, T_JOIN);
-    switch (n_bands) {
-        case 8: e = launch_join<8>(c, n_pad, rb, re); break;
-        case 16: e = launch_join<16>(c, n_pad, rb, re); break;
-        case 32: e = launch_join<32>(c, n_pad, rb, re); break;
-        case 64: e = launch_join<64>(c, n_pad, rb, re); break;
-        case 128: e = launch_join<128>(c, n_pad, rb, re); break;
-        default: return hipErrorInvalidValue;
-    }
+        TimerScope t(c, T_JOIN, io.st);
+        switch (n_bands) {
+            case 8: e = launch_join<8>(c, io, n_pad, rb, re); break;
+            case 16: e = launch_join<16>(c, io, n_pad, rb, re); break;
+            case 32: e = launch_join<32>(c, io, n_pad, rb, re); break;
+            case 64: e = launch_join<64>(c, io, n_pad, rb, re); break;
+            case 128: e = launch_join<128>(c, io, n_pad, rb, re); break;
+            default: return hipErrorInvalidValue;
+        }
     }
     if (e != hipSuccess) return e;
-    TimerScope t(c, T_VERIFY);
-    hipLaunchKernelGGL(verify_kernel, dim3(1024), dim3(kBlock), 0, c->stream, c->d_aux, c->m, n_rows, n_bands,
-                       c->cand.p, &c->pc.p->n_candidates, (u64)c->cand.cap, c->surv.p, (u64)c->surv.cap, c->pc.p);
+    TimerScope t(c, T_VERIFY, io.st);
+    hipLaunchKernelGGL(verify_kernel, dim3(1024), dim3(kBlock), 0, io.st, c->d_aux, c->m, n_rows, n_bands,
+                       io.cand, &io.pc->n_candidates, io.cap, io.surv, io.cap, io.pc);
     return hipGetLastError();
 }
 
@@ -364,7 +379,8 @@ long long pair_bound(long long n, long long rb, long long re) {
 }
 
 template <int CRIT>
-hipError_t launch_aux_filter(selhip_ctx* c, const selhip_int2_t* list, const u64* n_dev, u64 off, u64 len, u64 cap, double tau) {
+hipError_t launch_aux_filter(selhip_ctx* c, const selhip_int2_t* list, const u64* n_dev, u64 off, u64 len, u64 cap, double tau,
+                             u64* out_count) {
     const float Z = 1.96f;                                   // z_score, selection.cpp:76
     const float zs_f = Z * sigma_p_of(c->p_aux);             // float * float (criteria_sketch.hpp:29,40)
     const double zs = (double)zs_f;
@@ -373,11 +389,35 @@ hipError_t launch_aux_filter(selhip_ctx* c, const selhip_int2_t* list, const u64
     const unsigned grid = 2048;
     if (c->fp_mode == SELHIP_FP_FMA)
         hipLaunchKernelGGL((aux_filter_kernel<true, CRIT>), dim3(grid), dim3(kWave), 0, c->stream, c->counts.p, list, n_dev, off, len, cap,
-                           c->p_aux, rs, c->ecard.p, tau, zs, S_sum, c->fin.p, (u64)c->fin.cap, &c->pc.p->n_final);
+                           c->p_aux, rs, c->ecard.p, tau, zs, S_sum, c->fin.p, (u64)c->fin.cap, out_count);
     else
         hipLaunchKernelGGL((aux_filter_kernel<false, CRIT>), dim3(grid), dim3(kWave), 0, c->stream, c->counts.p, list, n_dev, off, len, cap,
-                           c->p_aux, rs, c->ecard.p, tau, zs, S_sum, c->fin.p, (u64)c->fin.cap, &c->pc.p->n_final);
+                           c->p_aux, rs, c->ecard.p, tau, zs, S_sum, c->fin.p, (u64)c->fin.cap, out_count);
     return hipGetLastError();
+}
+
+// equal-pair row boundaries of the triangle rows [rb, re) x columns (row, n): the same cut the multi-GPU drivers use
+void chunk_rows(long long n, long long rb, long long re, int chunks, long long* bnd) {
+    const double total = (double)pair_bound(n, rb, re);
+    bnd[0] = rb;
+    long long i = rb;
+    double acc = 0;
+    for (int c = 1; c < chunks; ++c) {
+        const double target = total * c / chunks;
+        while (i < re && acc < target) { acc += (double)(n - 1 - i); ++i; }
+        bnd[c] = i;
+    }
+    bnd[chunks] = re;
+}
+
+int pipeline_chunks(const selhip_ctx* c) {
+    if (c->criterion != SELHIP_CRIT_SMH_A) return 1;
+    // Measured on MI355X (gpurun_out/bench_pipe_*.json): overlapping the two stages does NOT pay --
+    // cfg3 0.61 -> 0.74 / 0.85 ms with 2 / 4 chunks, cfg4 5.05 -> 5.11 / 5.14 ms: the join (VALU issue) and the
+    // histogram kernel (VALU + LDS atomics + memory) contend for the same issue slots, and every chunk adds launches.
+    // So the automatic setting is OFF; the mechanism stays for workloads with a heavier memory-bound stage 2.
+    if (c->pipeline <= 1) return 1;
+    return std::min(c->pipeline, kMaxChunks);
 }
 
 int enqueue_pass(selhip_ctx* c) {
@@ -385,35 +425,79 @@ int enqueue_pass(selhip_ctx* c) {
     const int rb = (int)c->row_begin, re = (int)c->row_end;
     const double tau = (double)c->tau_f;            // float threshold widened, selection.cpp:81,164
     const int crit = c->criterion;
+    PassCounters* pc0 = c->pc.p;                    // block 0: z0, evaluated, results; blocks 1.. : one per row chunk
     TimerScope total(c, T_TOTAL);
-    HIPCHK(&c->err, hipMemsetAsync(c->pc.p, 0, sizeof(PassCounters), c->stream));
+    HIPCHK(&c->err, hipMemsetAsync(c->pc.p, 0, sizeof(PassCounters) * (kMaxChunks + 1), c->stream));
     {
         TimerScope t(c, T_PREP);
         hipLaunchKernelGGL(cb_bounds_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream,
-                           c->d_cards, n, tau, c->mode == SELHIP_MODE_CB_SMH ? 1 : 0, rb, re, c->ecard.p, c->hi.p, c->pc.p);
+                           c->d_cards, n, tau, c->mode == SELHIP_MODE_CB_SMH ? 1 : 0, rb, re, c->ecard.p, c->hi.p, pc0);
         HIPCHK(&c->err, hipGetLastError());
     }
-    // ---- first criterion: smh_a (stream / signature join) or the explicit pair space for hll_a / hll_an
+    const bool use_sig = (crit == SELHIP_CRIT_SMH_A || crit == SELHIP_CRIT_HLL_A_SMH_A) &&
+                         (c->algo == SELHIP_ALGO_SIG || c->algo == SELHIP_ALGO_AUTO) && sig_supported(c->m, c->n_rows, c->n_bands);
+    if ((crit == SELHIP_CRIT_SMH_A || crit == SELHIP_CRIT_HLL_A_SMH_A) && c->algo == SELHIP_ALGO_SIG && !use_sig) {
+        set_err(&c->err, "ALGO_SIG needs power-of-two rows and 8..128 bands (got %d x %d)", c->n_rows, c->n_bands);
+        return SELHIP_E_BADARG;
+    }
+    if (use_sig) HIPCHK(&c->err, launch_sig_build(c, c->n_rows, c->n_bands));
+
+    const int chunks = pipeline_chunks(c);
+    c->n_chunks_last = chunks;
+    if (chunks > 1) {
+        // ---- smh_a, pipelined over row chunks: stage 1 on one stream, stage 2 on another, chained by events.
+        long long bnd[kMaxChunks + 1];
+        chunk_rows(n, rb, re, chunks, bnd);
+        const u64 slice = (u64)c->surv.cap / (u64)chunks;
+        const u64 window = (u64)c->counts.cap / 64;
+        HIPCHK(&c->err, hipEventRecord(c->ev_start, c->stream));
+        HIPCHK(&c->err, hipStreamWaitEvent(c->st_stage1, c->ev_start, 0));
+        HIPCHK(&c->err, hipStreamWaitEvent(c->st_stage2, c->ev_start, 0));
+        for (int k = 0; k < chunks; ++k) {
+            StageIO io{c->st_stage1, c->cand.p + (size_t)k * slice, c->surv.p + (size_t)k * slice, slice, pc0 + 1 + k};
+            {
+                TimerScope t(c, T_STAGE1, io.st);
+                if (use_sig) HIPCHK(&c->err, launch_stage1_sig(c, io, c->n_rows, c->n_bands, (int)bnd[k], (int)bnd[k + 1]));
+                else         HIPCHK(&c->err, launch_stage1(c, io, c->n_rows, c->n_bands, (int)bnd[k], (int)bnd[k + 1]));
+            }
+            HIPCHK(&c->err, hipEventRecord(c->ev_chunk[k], c->st_stage1));
+            HIPCHK(&c->err, hipStreamWaitEvent(c->st_stage2, c->ev_chunk[k], 0));
+            for (u64 off = 0; off < slice; off += window) {
+                {
+                    TimerScope t(c, T_HIST, c->st_stage2);
+                    hipLaunchKernelGGL(hll_union_hist_kernel, dim3(2048), dim3(kBlock), 0, c->st_stage2,
+                                       c->d_hll, c->p, io.surv, &io.pc->n_survivors, (u64)0, slice, c->counts.p, off, window);
+                    HIPCHK(&c->err, hipGetLastError());
+                }
+                TimerScope t(c, T_SELECT, c->st_stage2);
+                HIPCHK(&c->err, launch_select<1>(c->fp_mode == SELHIP_FP_FMA, c->st_stage2, 4096, c->counts.p, &io.pc->n_survivors, 0,
+                                                 slice, c->p, nullptr, io.surv, c->ecard.p, tau,
+                                                 c->results.p, (u64)c->results.cap, pc0, nullptr, nullptr, off, window));
+            }
+        }
+        HIPCHK(&c->err, hipEventRecord(c->ev_end, c->st_stage2));          // stage 2 of the last chunk waited for all of stage 1
+        HIPCHK(&c->err, hipStreamWaitEvent(c->stream, c->ev_end, 0));
+        HIPCHK(&c->err, hipMemcpyAsync(c->h_pc, c->pc.p, sizeof(PassCounters) * (kMaxChunks + 1), hipMemcpyDeviceToHost, c->stream));
+        return SELHIP_OK;
+    }
+
+    // ---- single chunk: everything in order on the context's stream (counter block 1)
+    StageIO io{c->stream, c->cand.p, c->surv.p, (u64)c->surv.cap, pc0 + 1};
     const selhip_int2_t* final_list = c->surv.p;
-    const u64* final_count = &c->pc.p->n_survivors;
+    const u64* final_count = &io.pc->n_survivors;
     u64 final_cap = (u64)c->surv.cap;
     if (crit == SELHIP_CRIT_SMH_A || crit == SELHIP_CRIT_HLL_A_SMH_A) {
         TimerScope t(c, T_STAGE1);
-        const bool use_sig = (c->algo == SELHIP_ALGO_SIG || c->algo == SELHIP_ALGO_AUTO) && sig_supported(c->m, c->n_rows, c->n_bands);
-        if (c->algo == SELHIP_ALGO_SIG && !use_sig) {
-            set_err(&c->err, "ALGO_SIG needs power-of-two rows and 8..128 bands (got %d x %d)", c->n_rows, c->n_bands);
-            return SELHIP_E_BADARG;
-        }
-        if (use_sig) HIPCHK(&c->err, launch_stage1_sig(c, c->n_rows, c->n_bands, rb, re));
-        else         HIPCHK(&c->err, launch_stage1(c, c->n_rows, c->n_bands, rb, re));
+        if (use_sig) HIPCHK(&c->err, launch_stage1_sig(c, io, c->n_rows, c->n_bands, rb, re));
+        else         HIPCHK(&c->err, launch_stage1(c, io, c->n_rows, c->n_bands, rb, re));
     } else {
         TimerScope t(c, T_STAGE1);
         const int rows = re - rb;
         const long long blocks = (long long)rows * ((n + kBlock - 1) / kBlock);
         if (blocks > 0x7FFFFFFFll) { set_err(&c->err, "row range too large"); return SELHIP_E_BADARG; }
         if (blocks > 0) {
-            hipLaunchKernelGGL(enum_pairs_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, c->stream, n, c->hi.p, c->pc.p,
-                               rb, re, rows, c->cand.p, (u64)c->cand.cap, c->pc.p);
+            hipLaunchKernelGGL(enum_pairs_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, c->stream, n, c->hi.p, pc0,
+                               rb, re, rows, c->cand.p, (u64)c->cand.cap, io.pc);
             HIPCHK(&c->err, hipGetLastError());
         }
     }
@@ -421,7 +505,7 @@ int enqueue_pass(selhip_ctx* c) {
     if (crit != SELHIP_CRIT_SMH_A) {
         TimerScope t(c, T_AUX);
         const selhip_int2_t* list = crit == SELHIP_CRIT_HLL_A_SMH_A ? c->surv.p : c->cand.p;
-        const u64* n_dev = crit == SELHIP_CRIT_HLL_A_SMH_A ? &c->pc.p->n_survivors : &c->pc.p->n_aux_in;
+        const u64* n_dev = crit == SELHIP_CRIT_HLL_A_SMH_A ? &io.pc->n_survivors : &io.pc->n_aux_in;
         const u64 cap = crit == SELHIP_CRIT_HLL_A_SMH_A ? (u64)c->surv.cap : (u64)c->cand.cap;
         const u64 window = (u64)c->counts.cap / 64;
         const u64 bound = crit == SELHIP_CRIT_HLL_A_SMH_A ? cap : std::min<u64>(cap, (u64)pair_bound(n, rb, re));
@@ -429,11 +513,11 @@ int enqueue_pass(selhip_ctx* c) {
             hipLaunchKernelGGL(hll_union_hist_kernel, dim3(2048), dim3(kBlock), 0, c->stream,
                                c->d_aux_hll, c->p_aux, list, n_dev, (u64)0, cap, c->counts.p, off, window);
             HIPCHK(&c->err, hipGetLastError());
-            if (crit == SELHIP_CRIT_HLL_AN) HIPCHK(&c->err, launch_aux_filter<2>(c, list, n_dev, off, window, cap, tau));
-            else                            HIPCHK(&c->err, launch_aux_filter<1>(c, list, n_dev, off, window, cap, tau));
+            if (crit == SELHIP_CRIT_HLL_AN) HIPCHK(&c->err, launch_aux_filter<2>(c, list, n_dev, off, window, cap, tau, &io.pc->n_final));
+            else                            HIPCHK(&c->err, launch_aux_filter<1>(c, list, n_dev, off, window, cap, tau, &io.pc->n_final));
         }
         final_list = c->fin.p;
-        final_count = &c->pc.p->n_final;
+        final_count = &io.pc->n_final;
         final_cap = (u64)c->fin.cap;
     }
     // ---- final criterion: HLL-14 union estimate + Jaccard (selection.cpp:286-288), windows of the counts buffer
@@ -449,17 +533,24 @@ int enqueue_pass(selhip_ctx* c) {
             TimerScope t(c, T_SELECT);
             HIPCHK(&c->err, launch_select<1>(c->fp_mode == SELHIP_FP_FMA, c->stream, 4096, c->counts.p, final_count, 0,
                                              final_cap, c->p, nullptr, final_list, c->ecard.p, tau,
-                                             c->results.p, (u64)c->results.cap, c->pc.p, nullptr, nullptr, off, window));
+                                             c->results.p, (u64)c->results.cap, pc0, nullptr, nullptr, off, window));
         }
     }
-    HIPCHK(&c->err, hipMemcpyAsync(c->h_pc, c->pc.p, sizeof(PassCounters), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(&c->err, hipMemcpyAsync(c->h_pc, c->pc.p, sizeof(PassCounters) * (kMaxChunks + 1), hipMemcpyDeviceToHost, c->stream));
     return SELHIP_OK;
 }
 
 int ensure_scratch(selhip_ctx* c, size_t surv_cap, size_t res_cap) {
     HIPCHK(&c->err, c->ecard.ensure((size_t)c->n));
     HIPCHK(&c->err, c->hi.ensure((size_t)c->n));
-    HIPCHK(&c->err, c->pc.ensure(1));
+    HIPCHK(&c->err, c->pc.ensure(kMaxChunks + 1));
+    if (!c->st_stage1) {
+        HIPCHK(&c->err, hipStreamCreateWithFlags(&c->st_stage1, hipStreamNonBlocking));
+        HIPCHK(&c->err, hipStreamCreateWithFlags(&c->st_stage2, hipStreamNonBlocking));
+        HIPCHK(&c->err, hipEventCreateWithFlags(&c->ev_start, hipEventDisableTiming));
+        HIPCHK(&c->err, hipEventCreateWithFlags(&c->ev_end, hipEventDisableTiming));
+        for (int k = 0; k < kMaxChunks; ++k) HIPCHK(&c->err, hipEventCreateWithFlags(&c->ev_chunk[k], hipEventDisableTiming));
+    }
     HIPCHK(&c->err, c->surv.ensure(surv_cap));
     HIPCHK(&c->err, c->cand.ensure(surv_cap));
     if (c->criterion != SELHIP_CRIT_SMH_A) HIPCHK(&c->err, c->fin.ensure(surv_cap));
@@ -483,7 +574,7 @@ int ensure_scratch(selhip_ctx* c, size_t surv_cap, size_t res_cap) {
     // histogram scratch: 256 B per pair, at most 1 Mi pairs per window (256 MiB)
     HIPCHK(&c->err, c->counts.ensure(std::min<size_t>(std::max(c->surv.cap, (size_t)c->n), (size_t)1 << 20) * 64));
     HIPCHK(&c->err, c->results.ensure(res_cap));
-    if (!c->h_pc) HIPCHK(&c->err, hipHostMalloc((void**)&c->h_pc, sizeof(PassCounters), hipHostMallocDefault));
+    if (!c->h_pc) HIPCHK(&c->err, hipHostMalloc((void**)&c->h_pc, sizeof(PassCounters) * (kMaxChunks + 1), hipHostMallocDefault));
     return SELHIP_OK;
 }
 
@@ -538,6 +629,11 @@ void selhip_ctx_destroy(selhip_ctx* c) {
     c->counts.release(); c->results.release(); c->self_pairs.release();
     c->cand.release(); c->sigQ.release(); c->sigT.release(); c->fin.release(); c->own_aux_hll.release();
     if (c->h_pc) (void)hipHostFree(c->h_pc);
+    if (c->st_stage1) {
+        (void)hipStreamDestroy(c->st_stage1); (void)hipStreamDestroy(c->st_stage2);
+        (void)hipEventDestroy(c->ev_start); (void)hipEventDestroy(c->ev_end);
+        for (int k = 0; k < kMaxChunks; ++k) (void)hipEventDestroy(c->ev_chunk[k]);
+    }
     delete c;
 }
 
@@ -550,6 +646,12 @@ int selhip_ctx_set_stream(selhip_ctx* c, void* hip_stream) {
 int selhip_ctx_set_fp_mode(selhip_ctx* c, int fp_mode) {
     if (!c || (fp_mode != SELHIP_FP_FMA && fp_mode != SELHIP_FP_STRICT)) return SELHIP_E_BADARG;
     c->fp_mode = fp_mode;
+    return SELHIP_OK;
+}
+
+int selhip_ctx_set_pipeline(selhip_ctx* c, int chunks) {
+    if (!c || chunks < -1 || chunks > kMaxChunks) return SELHIP_E_BADARG;
+    c->pipeline = chunks;
     return SELHIP_OK;
 }
 
@@ -699,14 +801,20 @@ int selhip_ctx_finish(selhip_ctx* c) {
     HIPCHK(&c->err, hipSetDevice(c->device));
     for (int attempt = 0; attempt < 8; ++attempt) {
         HIPCHK(&c->err, hipStreamSynchronize(c->stream));
-        PassCounters pc = *c->h_pc;
+        // block 0 = pass-wide counters; blocks 1..chunks = per-row-chunk list counters (each list slice = cap / chunks)
+        PassCounters pc = c->h_pc[0];
+        const int chunks = c->n_chunks_last;
         if (pc.unsorted) { c->pending = false; set_err(&c->err, "cards are not in ascending order"); return SELHIP_E_BADARG; }
         bool grow = false;
         size_t surv_cap = c->surv.cap, res_cap = c->results.cap;
-        if (pc.n_survivors > c->surv.cap) { surv_cap = (size_t)(pc.n_survivors + pc.n_survivors / 8 + 1024); grow = true; }
-        if (pc.n_candidates > c->cand.cap) { surv_cap = std::max(surv_cap, (size_t)(pc.n_candidates + pc.n_candidates / 8 + 1024)); grow = true; }
-        if (c->criterion != SELHIP_CRIT_SMH_A && pc.n_final > c->fin.cap) { surv_cap = std::max(surv_cap, (size_t)(pc.n_final + pc.n_final / 8 + 1024)); grow = true; }
-        if (pc.n_aux_in > c->cand.cap) { c->pending = false; set_err(&c->err, "internal: enumerated pair list overflow"); return SELHIP_E_OVERFLOW; }
+        const size_t slice = c->surv.cap / (size_t)chunks;
+        for (int k = 1; k <= chunks; ++k) {
+            const PassCounters& q = c->h_pc[k];
+            pc.n_survivors += q.n_survivors; pc.n_candidates += q.n_candidates; pc.n_aux_in += q.n_aux_in; pc.n_final += q.n_final;
+            const u64 worst = std::max(std::max(q.n_survivors, q.n_candidates), c->criterion != SELHIP_CRIT_SMH_A ? q.n_final : 0);
+            if (worst > slice) { surv_cap = std::max(surv_cap, (size_t)((worst + worst / 8 + 1024) * (u64)chunks)); grow = true; }
+            if (q.n_aux_in > c->cand.cap) { c->pending = false; set_err(&c->err, "internal: enumerated pair list overflow"); return SELHIP_E_OVERFLOW; }
+        }
         if (pc.n_results > c->results.cap) { res_cap = (size_t)(pc.n_results + pc.n_results / 8 + 1024); grow = true; }
         if (!grow) {
             c->last = pc; c->pending = false; c->have_run = true;
@@ -806,9 +914,19 @@ int selhip_ctx_timing(selhip_ctx* c, int enable) {
 
 double selhip_ctx_kernel_ms(const selhip_ctx* c, const char* name) {
     if (!c || !name) return -1.0;
+    const long passes = c->timers[T_TOTAL].launches;
     for (int t = 0; t < T_COUNT; ++t)
         if (!std::strcmp(name, kTimerNames[t]))
-            return c->timers[t].launches ? c->timers[t].total_ms / (double)c->timers[t].launches : -1.0;
+            return (c->timers[t].launches && passes) ? c->timers[t].total_ms / (double)passes : -1.0;
+    return -1.0;
+}
+
+double selhip_ctx_kernel_launches(const selhip_ctx* c, const char* name) {
+    if (!c || !name) return -1.0;
+    const long passes = c->timers[T_TOTAL].launches;
+    for (int t = 0; t < T_COUNT; ++t)
+        if (!std::strcmp(name, kTimerNames[t]))
+            return passes ? (double)c->timers[t].launches / (double)passes : 0.0;
     return -1.0;
 }
 

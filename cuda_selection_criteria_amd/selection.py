@@ -153,6 +153,10 @@ class Selector:
         check(self._lib.selhip_ctx_attach_aux_hll(self._ctx, aux_hll_t.data_ptr(), p_aux), self._ctx)
         self._keep_aux = aux_hll_t
 
+    def set_pipeline(self, chunks: int):
+        """-1 auto, 0 off, 2..8 forced: overlap of stage 1 (next row chunk) with stage 2 (previous chunk)"""
+        check(self._lib.selhip_ctx_set_pipeline(self._ctx, chunks), self._ctx)
+
     def set_criterion(self, criterion: int):
         check(self._lib.selhip_ctx_set_criterion(self._ctx, criterion), self._ctx)
         self.criterion = criterion
@@ -219,7 +223,11 @@ class Selector:
         check(self._lib.selhip_ctx_timing(self._ctx, 1 if enable else 0), self._ctx)
 
     def kernel_ms(self, name: str) -> float:
+        """device ms per pass spent in the named kernel (sum over its launches of one pass)"""
         return float(self._lib.selhip_ctx_kernel_ms(self._ctx, name.encode()))
+
+    def kernel_launches(self, name: str) -> float:
+        return float(self._lib.selhip_ctx_kernel_launches(self._ctx, name.encode()))
 
 
 def select_from_filelist(list_file: str, tau: float, aux_bytes: int, mode: int = MODE_CB_SMH, device: int = 0,

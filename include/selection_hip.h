@@ -108,6 +108,10 @@ const char* selhip_last_error(const selhip_ctx* ctx);
 
 /* Run all work of this context on `hip_stream` (a hipStream_t passed as void*; NULL = null stream). */
 int selhip_ctx_set_stream(selhip_ctx* ctx, void* hip_stream);
+/* Stage pipeline of a pass: the query rows are cut into `chunks` equal-pair chunks; stage 1 (all-pairs, VALU-bound)
+ * of chunk c+1 runs on one internal stream while stage 2 (HLL union histograms, memory/LDS-bound) of chunk c runs on
+ * another.  -1 / 0 / 1 = off (the default: measured slower or equal on MI355X), 2..8 = chunk count. */
+int selhip_ctx_set_pipeline(selhip_ctx* ctx, int chunks);
 /* SELHIP_FP_FMA (default) or SELHIP_FP_STRICT */
 int selhip_ctx_set_fp_mode(selhip_ctx* ctx, int fp_mode);
 
@@ -164,9 +168,12 @@ int selhip_ctx_copy_results(selhip_ctx* ctx, selhip_pair_t* d_dst, int64_t cap);
  * d_dst must hold cap_records + 1 records.  Returns SELHIP_E_OVERFLOW (after copying cap_records) if count > cap. */
 int selhip_ctx_copy_results_framed(selhip_ctx* ctx, void* d_dst, int64_t cap_records);
 
-/* average device time (ms, HIP events on the context's stream) of the named kernel over the launches
- * since the last reset; names: "stage1", "hist", "select", "prep", "total".  <0 if never launched. */
+/* device time (ms, HIP events on the stream each kernel is launched on) of the named kernel PER PASS, averaged over
+ * the passes since the last reset (a pipelined pass launches a kernel once per row chunk: the figure is their sum);
+ * names: "prep", "sigbuild", "join", "verify", "stage1", "aux", "hist", "select", "total".  <0 if never launched.
+ * selhip_ctx_kernel_launches: launches of that kernel per pass. */
 double selhip_ctx_kernel_ms(const selhip_ctx* ctx, const char* name);
+double selhip_ctx_kernel_launches(const selhip_ctx* ctx, const char* name);
 int    selhip_ctx_timing(selhip_ctx* ctx, int enable);   /* enable/disable + reset event timing */
 
 /* ---------------------------------------------------------------------------------------------------

@@ -165,6 +165,25 @@ def test_row_shards_union_equals_whole(oracle):
             assert len(whole) > 1000
 
 
+def test_pipelined_pass_equals_plain(oracle):
+    """stage 1 / stage 2 of row chunks on two internal streams (selhip_ctx_set_pipeline): same pairs, same counters"""
+    cfg = make_golden.GOLDEN_SYNTH["synth_flat_n1000_m256"]
+    hll, aux, cards, _, _ = sorted_set(cfg, oracle)
+    r, b = pkg.banding(cfg.m, cfg.tau)
+    want, st = oracle.select(hll, aux, cards, cfg.tau, r, b)
+    with Selector(0) as sel:
+        sel.upload(hll, aux, cards)
+        for chunks in (0, 2, 3, 4, 8):
+            sel.set_pipeline(chunks)
+            for algo in (ALGO_SIG, ALGO_STREAM):
+                for rows in (None, (100, 900)):
+                    got = sel.run(cfg.tau, MODE_CB_SMH, r, b, algo=algo, rows=rows)
+                    w = want if rows is None else want[(want["i"] >= rows[0]) & (want["i"] < rows[1])]
+                    assert_same_pairs(got, w)
+            s = sel.stats()
+            assert s["survivors"] == len(w)        # every survivor of this set is selected
+
+
 def test_edge_cases(oracle):
     cfg = SynthConfig("edge", 130, 128, 0.9, 77, n_sh_lo=5000, n_sh_hi=5000)
     hll, aux, cards, _, _ = sorted_set(cfg, oracle)
