@@ -1077,11 +1077,10 @@ int selhip_synth_generate(const selhip_synth_t* sp_in, int64_t g_begin, int64_t 
     sp.seed = sp_in->seed; sp.n_genomes = sp_in->n_genomes; sp.m = sp_in->m; sp.p_aux = sp_in->p_aux;
     sp.cluster_size = sp_in->cluster_size; sp.mode = sp_in->mode; sp.n_sh_lo = sp_in->n_sh_lo; sp.n_sh_hi = sp_in->n_sh_hi;
     const size_t smem = (size_t)sp.m * 8 + 16384 * 4 + (sp.p_aux ? ((size_t)4 << sp.p_aux) : 0);
-    static bool attr_set = false;
-    if (!attr_set) {
-        HIPCHK(nullptr, hipFuncSetAttribute((const void*)synth_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
-    }
+    static std::once_flag once;
+    static hipError_t attr_err = hipSuccess;
+    std::call_once(once, [] { attr_err = hipFuncSetAttribute((const void*)synth_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); });
+    HIPCHK(nullptr, attr_err);
     hipLaunchKernelGGL(synth_kernel, dim3((unsigned)(g_end - g_begin)), dim3(kBlock), smem, (hipStream_t)hip_stream,
                        sp, (long long)g_begin, (long long)g_end, d_hll, (u64*)d_aux, d_aux_hll);
     HIPCHK(nullptr, hipGetLastError());
@@ -1097,11 +1096,10 @@ int selhip_build_sketches(const uint8_t* d_codes, const int64_t* d_offsets, int6
     if (n_genomes == 0) return SELHIP_OK;
     const size_t ms = d_smh ? (size_t)m : 0;
     const size_t smem = ms * 8 + 16384 + (d_aux_hll ? ((((size_t)1 << p_aux) + 3) / 4 * 4) : 0) + ms * 12 + 16;
-    static bool attr_set = false;
-    if (!attr_set) {
-        HIPCHK(nullptr, hipFuncSetAttribute((const void*)sketch_build_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
-    }
+    static std::once_flag once;
+    static hipError_t attr_err = hipSuccess;
+    std::call_once(once, [] { attr_err = hipFuncSetAttribute((const void*)sketch_build_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); });
+    HIPCHK(nullptr, attr_err);
     hipLaunchKernelGGL(sketch_build_kernel, dim3((unsigned)n_genomes), dim3(kBlock), smem, (hipStream_t)hip_stream,
                        d_codes, (const long long*)d_offsets, k, m, p_aux, d_hll, (u64*)d_smh, d_aux_hll);
     HIPCHK(nullptr, hipGetLastError());
