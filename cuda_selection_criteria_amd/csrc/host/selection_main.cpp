@@ -7,7 +7,8 @@
 //   -h <tau>    similarity threshold (float, std::stof like selection.cpp:103)
 //   -a <bytes>  auxiliary memory per genome; m = bytes/8 SuperMinHash buckets (selection.cpp:231)
 //   -b <n>      accepted for CLI compatibility (CUDA block size in the reference); ignored
-//   -c <crit>   accepted; only smh_a is implemented by this path (selection_cuda.cpp:64 ignores it too)
+//   -c <crit>   smh_a (default; the only criterion of the reference's GPU driver, selection_cuda.cpp:64), or hll_a /
+//               hll_an as in the CPU program (src/selection.cpp:122-227: auxiliary HLL p = ctz(aux_bytes), file .hll_<p>)
 //   -t <n>      host threads for loading sketches (selection.cpp:97)
 //   -g <n>      number of GPUs to shard the pair space over (default 1)
 //   -n          no CB pruning ("smh_a" mode of experiments/src/time_smh.cpp:229-257)
@@ -50,20 +51,28 @@ int main(int argc, char* argv[]) {
             default: break;
         }
     }
-    if (criterion != "smh_a") {
-        std::cout << "Option -c invalid. This program implements the smh_a criterion.\n";
+    int crit = SELHIP_CRIT_SMH_A;
+    if (criterion == "hll_a") crit = SELHIP_CRIT_HLL_A;
+    else if (criterion == "hll_an") crit = SELHIP_CRIT_HLL_AN;
+    else if (criterion != "smh_a") {
+        std::cout << "Option -c invalid. The accepted criteria are hll_a, hll_an and smh_a.\n";    // selection.cpp:293
         return 0;
     }
     if (list_file.empty()) { std::cerr << "No input file provided\n"; exit(-1); }   // selection.cpp:40-44
-    const unsigned m = (unsigned)aux_bytes / 8;
+    const unsigned m = crit == SELHIP_CRIT_SMH_A ? (unsigned)aux_bytes / 8 : 0;                      // selection.cpp:231
+    const unsigned p_aux = crit == SELHIP_CRIT_SMH_A ? 0 : (unsigned)__builtin_ctz(aux_bytes ? aux_bytes : 1);   // :125
 
     selhost_dataset* ds = nullptr;
-    int rc = selhost_dataset_load(&ds, list_file.c_str(), m, 0, fp_mode, threads);
+    int rc = selhost_dataset_load(&ds, list_file.c_str(), m, p_aux, fp_mode, threads);
     if (rc) { std::cerr << selhost_last_error() << "\n"; exit(-1); }
     const int64_t n = selhost_dataset_size(ds);
 
     int n_rows = 1, n_bands = 1;
-    selhost_banding(m, threshold, SELHOST_BANDING_CPU, &n_rows, &n_bands);
+    if (m) selhost_banding(m, threshold, SELHOST_BANDING_CPU, &n_rows, &n_bands);
+    // hll_a / hll_an do not read SuperMinHash buckets: a one-bucket placeholder keeps the upload call uniform
+    std::vector<uint64_t> no_smh(m ? 0 : (size_t)(n > 0 ? n : 1), 0);
+    const uint64_t* aux_ptr = m ? selhost_dataset_aux(ds) : no_smh.data();
+    const int m_up = m ? (int)m : 1;
 
     const int avail = selhip_device_count();
     if (avail <= 0) { std::cerr << "selection: no MI355X (gfx950) device available: " << selhip_last_error(nullptr) << "\n"; return 3; }
@@ -82,7 +91,9 @@ int main(int argc, char* argv[]) {
         int r = selhip_ctx_create(&ctx, g);
         if (r) { status[(size_t)g] = r; errs[(size_t)g] = selhip_last_error(nullptr); return; }
         selhip_ctx_set_fp_mode(ctx, fp_mode);
-        r = selhip_ctx_upload(ctx, selhost_dataset_hll(ds), selhost_dataset_aux(ds), selhost_dataset_cards(ds), n, (int)m, 14);
+        r = selhip_ctx_upload(ctx, selhost_dataset_hll(ds), aux_ptr, selhost_dataset_cards(ds), n, m_up, 14);
+        if (!r && p_aux) r = selhip_ctx_upload_aux_hll(ctx, selhost_dataset_aux_hll(ds), (int)p_aux);
+        if (!r) r = selhip_ctx_set_criterion(ctx, crit);
         if (!r) r = selhip_ctx_run(ctx, mode, algo, threshold, n_rows, n_bands, bounds[(size_t)g], bounds[(size_t)g + 1]);
         if (!r) {
             int64_t cnt = selhip_ctx_result_count(ctx);

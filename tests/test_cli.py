@@ -36,6 +36,16 @@ def test_selection_cli_matches_reference_stdout(a, h):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("crit", ["hll_a", "hll_an"])
+def test_selection_cli_hll_criteria(crit):
+    for h in ("0.9", "0.01"):
+        out = subprocess.run([str(BIN / "selection"), "-l", "influenza_filelist.txt", "-h", h, "-a", "256", "-c", crit],
+                             cwd=GOLDEN, capture_output=True, text=True)
+        assert out.returncode == 0, out.stderr
+        assert out.stdout == (EXP / f"influenza_{crit}_a256_h{h}.fma.txt").read_text()
+
+
+@pytest.mark.gpu
 def test_time_smh_hip_records():
     out = subprocess.run([str(BIN / "time_smh_hip"), "-l", "influenza_filelist.txt", "-h", "0.9", "-m", "256", "-b", "256"],
                          cwd=GOLDEN, capture_output=True, text=True)
