@@ -10,7 +10,7 @@
 //   -c <crit>   smh_a (default; the only criterion of the reference's GPU driver, selection_cuda.cpp:64), or hll_a /
 //               hll_an as in the CPU program (src/selection.cpp:122-227: auxiliary HLL p = ctz(aux_bytes), file .hll_<p>)
 //   -t <n>      host threads for loading sketches (selection.cpp:97)
-//   -g <n>      number of GPUs to shard the pair space over (default 1)
+//   -g <n>      number of GPUs to shard the pair space over (default 1); selected pairs gathered over RCCL/xGMI
 //   -n          no CB pruning ("smh_a" mode of experiments/src/time_smh.cpp:229-257)
 //   -A <algo>   stage-1 algorithm: auto | stream | sig
 //   -F <0|1>    estimator flavour: 1 = FMA (reference Makefile build on FMA hosts, default), 0 = strict
@@ -22,7 +22,6 @@
 #include <cstring>
 #include <iostream>
 #include <string>
-#include <thread>
 #include <vector>
 
 #include "../../../include/selection_hip.h"
@@ -79,38 +78,42 @@ int main(int argc, char* argv[]) {
     if (n_gpus < 1) n_gpus = 1;
     if (n_gpus > avail) n_gpus = avail;
 
-    std::vector<int64_t> bounds((size_t)n_gpus + 1);
-    // equal-pair-count row shards; the CB cut-off only shortens rows, the triangular estimate is used here
-    selhost_shard_rows(n, nullptr, 0, n_gpus, bounds.data());
-
-    std::vector<std::vector<selhip_pair_t>> parts((size_t)n_gpus);
-    std::vector<int> status((size_t)n_gpus, 0);
-    std::vector<std::string> errs((size_t)n_gpus);
-    auto worker = [&](int g) {
+    std::vector<std::vector<selhip_pair_t>> parts(1);
+    if (n_gpus > 1 && crit == SELHIP_CRIT_SMH_A) {
+        // one process, one thread + context per device, selected pairs gathered over RCCL/xGMI (host merge if RCCL is
+        // unavailable): selhip_multi_select
+        std::vector<int> devs((size_t)n_gpus);
+        for (int g = 0; g < n_gpus; ++g) devs[(size_t)g] = g;
+        int64_t cnt = 0, cap = 1 << 20;
+        for (int attempt = 0; attempt < 2; ++attempt) {
+            parts[0].resize((size_t)cap);
+            int r = selhip_multi_select(devs.data(), n_gpus, selhost_dataset_hll(ds), aux_ptr, selhost_dataset_cards(ds), n, m_up, 14,
+                                        mode, algo, fp_mode, threshold, n_rows, n_bands, SELHIP_GATHER_RCCL_OR_HOST,
+                                        parts[0].data(), cap, &cnt, nullptr);
+            if (r == SELHIP_E_OVERFLOW && attempt == 0) { cap = cnt; continue; }
+            if (r) { std::cerr << "selection: " << selhip_last_error(nullptr) << "\n"; return 4; }
+            break;
+        }
+        parts[0].resize((size_t)cnt);
+        n_gpus = 1;                                   // one merged, sorted part
+    } else {
+        n_gpus = 1;
         selhip_ctx* ctx = nullptr;
-        int r = selhip_ctx_create(&ctx, g);
-        if (r) { status[(size_t)g] = r; errs[(size_t)g] = selhip_last_error(nullptr); return; }
+        int r = selhip_ctx_create(&ctx, 0);
+        if (r) { std::cerr << "selection: " << selhip_last_error(nullptr) << "\n"; return 4; }
         selhip_ctx_set_fp_mode(ctx, fp_mode);
         r = selhip_ctx_upload(ctx, selhost_dataset_hll(ds), aux_ptr, selhost_dataset_cards(ds), n, m_up, 14);
         if (!r && p_aux) r = selhip_ctx_upload_aux_hll(ctx, selhost_dataset_aux_hll(ds), (int)p_aux);
         if (!r) r = selhip_ctx_set_criterion(ctx, crit);
-        if (!r) r = selhip_ctx_run(ctx, mode, algo, threshold, n_rows, n_bands, bounds[(size_t)g], bounds[(size_t)g + 1]);
+        if (!r) r = selhip_ctx_run(ctx, mode, algo, threshold, n_rows, n_bands, 0, n);
         if (!r) {
             int64_t cnt = selhip_ctx_result_count(ctx);
-            parts[(size_t)g].resize((size_t)cnt);
-            r = selhip_ctx_fetch(ctx, parts[(size_t)g].data(), cnt);
+            parts[0].resize((size_t)cnt);
+            r = selhip_ctx_fetch(ctx, parts[0].data(), cnt);
         }
-        if (r) { status[(size_t)g] = r; errs[(size_t)g] = selhip_last_error(ctx); }
+        if (r) { std::cerr << "selection: " << selhip_last_error(ctx) << "\n"; selhip_ctx_destroy(ctx); return 4; }
         selhip_ctx_destroy(ctx);
-    };
-    if (n_gpus == 1) worker(0);
-    else {
-        std::vector<std::thread> th;
-        for (int g = 0; g < n_gpus; ++g) th.emplace_back(worker, g);
-        for (auto& t : th) t.join();
     }
-    for (int g = 0; g < n_gpus; ++g)
-        if (status[(size_t)g]) { std::cerr << "selection: GPU " << g << ": " << errs[(size_t)g] << "\n"; return 4; }
 
     // shards are contiguous row ranges and each part is sorted by (i,k): concatenation = print order
     std::string out;

@@ -20,6 +20,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <array>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -1065,6 +1066,167 @@ int launch_kernel_CBsmh(const uint8_t* main_sketches, const uint64_t* aux_sketch
                         selhip_result_t* out, int* out_count, int blockSize) {
     (void)blockSize;
     return compat_launch(true, main_sketches, aux_sketches, cards, pairs, total_pairs, tau, m_aux, m_hll, n_rows, n_bands, out, out_count);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Multi-GPU entry taking a device list (one host thread per device inside ONE process): the pair space is sharded by
+// query rows (equal pair counts), every device holds a full replica of the sketches, and the only exchange step is
+// the gather of the selected-pair records -- RCCL all_gather over xGMI (counts first, then max-count-sized framed
+// buffers), librccl loaded with dlopen so that single-GPU users never pay for it.  (bench.py uses the equivalent
+// process-per-GPU layout through torch.distributed.)
+// ---------------------------------------------------------------------------------------------------
+}  // extern "C"
+
+#include <dlfcn.h>
+#include <thread>
+
+namespace {
+
+struct Rccl {
+    void* lib = nullptr;
+    int (*CommInitAll)(void**, int, const int*) = nullptr;
+    int (*CommDestroy)(void*) = nullptr;
+    int (*AllGather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
+    const char* (*GetErrorString)(int) = nullptr;
+    bool load() {
+        if (lib) return true;
+        for (const char* name : {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"}) {
+            lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+            if (lib) break;
+        }
+        if (!lib) return false;
+        CommInitAll = (int (*)(void**, int, const int*))dlsym(lib, "ncclCommInitAll");
+        CommDestroy = (int (*)(void*))dlsym(lib, "ncclCommDestroy");
+        AllGather = (int (*)(const void*, void*, size_t, int, void*, hipStream_t))dlsym(lib, "ncclAllGather");
+        GetErrorString = (const char* (*)(int))dlsym(lib, "ncclGetErrorString");
+        return CommInitAll && CommDestroy && AllGather && GetErrorString;
+    }
+};
+Rccl g_rccl;
+constexpr int kNcclChar = 0;     // ncclDataType_t ncclChar (rccl.h)
+
+// equal-pair row boundaries over [0, n) for `parts` devices (triangular pair space)
+void shard_rows_host(long long n, int parts, std::vector<long long>& bnd) {
+    bnd.assign((size_t)parts + 1, 0);
+    std::vector<long long> tmp((size_t)parts + 1);
+    chunk_rows(n, 0, n, parts, tmp.data());
+    for (int k = 0; k <= parts; ++k) bnd[(size_t)k] = tmp[(size_t)k];
+}
+
+}  // namespace
+
+extern "C" {
+
+int selhip_multi_select(const int* devices, int n_devices,
+                        const uint8_t* h_hll, const uint64_t* h_aux, const double* h_cards,
+                        int64_t n, int m, int p_hll, int mode, int algo, int fp_mode, float tau_f, int n_rows, int n_bands,
+                        int gather, selhip_pair_t* h_out, int64_t cap, int64_t* count_out, int64_t stats_out[4]) {
+    if (!devices || n_devices < 1 || n_devices > 64 || !count_out || cap < 0 || (cap && !h_out)) { set_err(nullptr, "bad argument"); return SELHIP_E_BADARG; }
+    if (gather < SELHIP_GATHER_HOST || gather > SELHIP_GATHER_RCCL_OR_HOST) { set_err(nullptr, "bad gather mode"); return SELHIP_E_BADARG; }
+    *count_out = 0;
+    const int G = n_devices;
+    std::vector<long long> bnd;
+    shard_rows_host(n, G, bnd);
+
+    // RCCL communicators (single process, one per device)
+    std::vector<void*> comms((size_t)G, nullptr);
+    bool use_rccl = gather != SELHIP_GATHER_HOST;
+    std::string rccl_note;
+    if (use_rccl) {
+        if (!g_rccl.load()) { use_rccl = false; rccl_note = "librccl.so not loadable"; }
+        else {
+            int r = g_rccl.CommInitAll(comms.data(), G, devices);
+            if (r != 0) { use_rccl = false; rccl_note = std::string("ncclCommInitAll: ") + g_rccl.GetErrorString(r); }
+        }
+        if (!use_rccl && gather == SELHIP_GATHER_RCCL) { set_err(nullptr, "RCCL gather requested but unavailable: %s", rccl_note.c_str()); return SELHIP_E_HIP; }
+    }
+
+    std::vector<selhip_ctx*> ctxs((size_t)G, nullptr);
+    std::vector<int> rc((size_t)G, 0);
+    std::vector<std::string> errs((size_t)G);
+    std::vector<std::vector<selhip_pair_t>> parts((size_t)G);
+    std::vector<int64_t> counts((size_t)G, 0);
+    std::vector<std::array<int64_t, 4>> st((size_t)G);
+    // phase 1: every device runs its shard
+    {
+        std::vector<std::thread> th;
+        for (int g = 0; g < G; ++g) th.emplace_back([&, g] {
+            int r = selhip_ctx_create(&ctxs[(size_t)g], devices[g]);
+            if (r) { rc[(size_t)g] = r; errs[(size_t)g] = selhip_last_error(nullptr); return; }
+            selhip_ctx* c = ctxs[(size_t)g];
+            r = selhip_ctx_set_fp_mode(c, fp_mode);
+            if (!r) r = selhip_ctx_upload(c, h_hll, h_aux, h_cards, n, m, p_hll);
+            if (!r) r = selhip_ctx_run(c, mode, algo, tau_f, n_rows, n_bands, bnd[(size_t)g], bnd[(size_t)g + 1]);
+            if (!r) { counts[(size_t)g] = selhip_ctx_result_count(c); r = selhip_ctx_stats(c, st[(size_t)g].data()); }
+            if (r) { rc[(size_t)g] = r; errs[(size_t)g] = selhip_last_error(c); }
+        });
+        for (auto& t : th) t.join();
+    }
+    int fail = 0;
+    for (int g = 0; g < G; ++g) if (rc[(size_t)g]) { fail = rc[(size_t)g]; set_err(nullptr, "device %d: %s", devices[g], errs[(size_t)g].c_str()); }
+    std::vector<selhip_pair_t> all;
+    if (!fail) {
+        int64_t max_cnt = 0, total = 0;
+        for (int g = 0; g < G; ++g) { max_cnt = std::max(max_cnt, counts[(size_t)g]); total += counts[(size_t)g]; }
+        if (use_rccl) {
+            // phase 2: framed send buffers of (max_cnt + 1) records, one all_gather, device 0's copy goes to the host
+            const size_t frame = (size_t)(max_cnt + 1) * sizeof(selhip_pair_t);
+            std::vector<void*> send((size_t)G, nullptr), recv((size_t)G, nullptr);
+            std::vector<std::thread> th;
+            std::vector<char> host_recv;
+            for (int g = 0; g < G; ++g) th.emplace_back([&, g] {
+                selhip_ctx* c = ctxs[(size_t)g];
+                hipError_t e = hipSetDevice(devices[g]);
+                if (e == hipSuccess) e = hipMalloc(&send[(size_t)g], frame);
+                if (e == hipSuccess) e = hipMalloc(&recv[(size_t)g], frame * (size_t)G);
+                if (e == hipSuccess) e = hipMemsetAsync(send[(size_t)g], 0, frame, c->stream);
+                if (e != hipSuccess) { rc[(size_t)g] = SELHIP_E_HIP; errs[(size_t)g] = hipGetErrorString(e); return; }
+                int r = selhip_ctx_copy_results_framed(c, send[(size_t)g], max_cnt);
+                if (r) { rc[(size_t)g] = r; errs[(size_t)g] = selhip_last_error(c); return; }
+                int nr = g_rccl.AllGather(send[(size_t)g], recv[(size_t)g], frame, kNcclChar, comms[(size_t)g], c->stream);
+                if (nr != 0) { rc[(size_t)g] = SELHIP_E_HIP; errs[(size_t)g] = std::string("ncclAllGather: ") + g_rccl.GetErrorString(nr); return; }
+                e = hipStreamSynchronize(c->stream);
+                if (e != hipSuccess) { rc[(size_t)g] = SELHIP_E_HIP; errs[(size_t)g] = hipGetErrorString(e); }
+            });
+            for (auto& t : th) t.join();
+            for (int g = 0; g < G; ++g) if (rc[(size_t)g]) { fail = rc[(size_t)g]; set_err(nullptr, "gather on device %d: %s", devices[g], errs[(size_t)g].c_str()); }
+            if (!fail) {
+                host_recv.resize(frame * (size_t)G);
+                (void)hipSetDevice(devices[0]);
+                if (hipMemcpy(host_recv.data(), recv[0], host_recv.size(), hipMemcpyDeviceToHost) != hipSuccess) { fail = SELHIP_E_HIP; set_err(nullptr, "copy of the gathered records failed"); }
+                for (int g = 0; g < G && !fail; ++g) {
+                    const char* f = host_recv.data() + (size_t)g * frame;
+                    uint64_t cnt;
+                    std::memcpy(&cnt, f, 8);
+                    if ((int64_t)cnt != counts[(size_t)g]) { fail = SELHIP_E_HIP; set_err(nullptr, "gathered count mismatch on rank %d", g); break; }
+                    const selhip_pair_t* rec = reinterpret_cast<const selhip_pair_t*>(f + sizeof(selhip_pair_t));
+                    all.insert(all.end(), rec, rec + cnt);
+                }
+            }
+            for (int g = 0; g < G; ++g) { (void)hipSetDevice(devices[g]); if (send[(size_t)g]) (void)hipFree(send[(size_t)g]); if (recv[(size_t)g]) (void)hipFree(recv[(size_t)g]); }
+        } else {
+            for (int g = 0; g < G && !fail; ++g) {
+                parts[(size_t)g].resize((size_t)counts[(size_t)g]);
+                int r = selhip_ctx_fetch(ctxs[(size_t)g], parts[(size_t)g].data(), counts[(size_t)g]);
+                if (r) { fail = r; set_err(nullptr, "fetch on device %d: %s", devices[g], selhip_last_error(ctxs[(size_t)g])); }
+                all.insert(all.end(), parts[(size_t)g].begin(), parts[(size_t)g].end());
+            }
+        }
+        if (!fail) {
+            std::sort(all.begin(), all.end(), [](const selhip_pair_t& a, const selhip_pair_t& b) { return a.i != b.i ? a.i < b.i : a.k < b.k; });
+            *count_out = (int64_t)all.size();
+            std::memcpy(h_out, all.data(), (size_t)std::min<int64_t>((int64_t)all.size(), cap) * sizeof(selhip_pair_t));
+            if (stats_out) {
+                for (int k = 0; k < 4; ++k) { stats_out[k] = 0; for (int g = 0; g < G; ++g) stats_out[k] += st[(size_t)g][(size_t)k]; }
+            }
+            if ((int64_t)all.size() > cap) fail = SELHIP_E_OVERFLOW;
+            (void)total;
+        }
+    }
+    for (int g = 0; g < G; ++g) if (ctxs[(size_t)g]) selhip_ctx_destroy(ctxs[(size_t)g]);
+    if (use_rccl) for (int g = 0; g < G; ++g) if (comms[(size_t)g]) (void)g_rccl.CommDestroy(comms[(size_t)g]);
+    if (!fail && !rccl_note.empty()) set_err(nullptr, "note: host gather used (%s)", rccl_note.c_str());
+    return fail;
 }
 
 // ---- synthetic data ----------------------------------------------------------------------------

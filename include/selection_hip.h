@@ -177,6 +177,21 @@ double selhip_ctx_kernel_launches(const selhip_ctx* ctx, const char* name);
 int    selhip_ctx_timing(selhip_ctx* ctx, int enable);   /* enable/disable + reset event timing */
 
 /* ---------------------------------------------------------------------------------------------------
+ * 2b. Multi-GPU entry taking a device list: ONE process, one host thread + one context per
+ *     device; the pair space is cut into equal-pair row ranges, every device gets a full replica of the (host)
+ *     sketches, and the selected-pair lists are gathered -- over RCCL/xGMI (ncclAllGather of framed record buffers on
+ *     communicators from ncclCommInitAll; librccl is dlopen'ed on first use) or through the host.
+ *     criterion smh_a.  h_out receives min(count, cap) records sorted by (i,k); stats_out (optional) as selhip_ctx_stats.
+ * --------------------------------------------------------------------------------------------------- */
+#define SELHIP_GATHER_HOST           0   /* each device's list is fetched and merged on the host              */
+#define SELHIP_GATHER_RCCL           1   /* RCCL all_gather; an error if RCCL cannot be initialised           */
+#define SELHIP_GATHER_RCCL_OR_HOST   2   /* RCCL if it initialises, host merge otherwise (note in last_error) */
+int selhip_multi_select(const int* devices, int n_devices,
+                        const uint8_t* h_hll, const uint64_t* h_aux, const double* h_cards,
+                        int64_t n_genomes, int m, int p_hll, int mode, int algo, int fp_mode, float tau_f, int n_rows, int n_bands,
+                        int gather, selhip_pair_t* h_out, int64_t cap, int64_t* count_out, int64_t stats_out[4]);
+
+/* ---------------------------------------------------------------------------------------------------
  * 3. Building blocks (device pointers), used by the launchers above and exposed for tests.
  * --------------------------------------------------------------------------------------------------- */
 /* smh_a on an explicit pair list: d_flags[j] = 1 iff pair j has a fully equal band. */

@@ -402,3 +402,21 @@ def test_unsorted_cards_rejected(oracle):
     with Selector(0) as sel:
         with pytest.raises(pkg.SelhipError):
             sel.upload(hll, aux, cards[::-1].copy())
+
+
+def test_multi_device_entry_and_rccl_gather(oracle):
+    """selhip_multi_select (device list, one process): RCCL all_gather with one rank, host merge with several
+    contexts sharing the one card, RCCL-or-host fallback when RCCL refuses duplicate devices"""
+    from cuda_selection_criteria_amd.selection import multi_select
+    cfg = make_golden.GOLDEN_SYNTH["synth_flat_n1000_m256"]
+    hll, aux, cards, _, _ = sorted_set(cfg, oracle)
+    r, b = pkg.banding(cfg.m, cfg.tau)
+    want, st = oracle.select(hll, aux, cards, cfg.tau, r, b)
+    for devices, gather in (([0], 1), ([0], 0), ([0, 0, 0], 0), ([0, 0], 2)):
+        got, s = multi_select(devices, hll, aux, cards, cfg.tau, MODE_CB_SMH, r, b, gather=gather)
+        assert_same_pairs(got, want)
+        assert s["evaluated"] == st["evaluated"] and s["survivors"] == st["survivors"], (devices, gather, s, st)
+    with pytest.raises(pkg.SelhipError):
+        multi_select([0, 0], hll, aux, cards, cfg.tau, MODE_CB_SMH, r, b, gather=1)      # RCCL required, duplicate GPU
+    with pytest.raises(pkg.SelhipError):
+        multi_select([7], hll, aux, cards, cfg.tau, MODE_CB_SMH, r, b, gather=0)         # no such device
