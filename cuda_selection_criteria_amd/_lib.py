@@ -40,7 +40,7 @@ class Synth(C.Structure):
 
 
 MODE_SMH, MODE_CB_SMH = 0, 1
-ALGO_AUTO, ALGO_STREAM, ALGO_SIG = 0, 1, 2
+ALGO_AUTO, ALGO_STREAM, ALGO_SIG, ALGO_HASHJOIN = 0, 1, 2, 3
 FP_STRICT, FP_FMA = 0, 1
 CRIT_SMH_A, CRIT_HLL_A, CRIT_HLL_AN, CRIT_HLL_A_SMH_A = 0, 1, 2, 3
 BANDING_CPU, BANDING_CUDA = 0, 1

@@ -150,4 +150,64 @@ void verify_kernel(const u64* __restrict__ aux, int m, int n_rows, int n_bands,
     }
 }
 
+// =============================================================================================
+// ALGO_HASHJOIN -- sub-quadratic candidate generation (NOT the brute-force metric's path):
+// instead of comparing every pair's signatures, sort the (band, signature) keys of all genomes (rocPRIM radix sort,
+// 32 + log2(NB) key bits) and read the candidates off the runs of equal keys.  A pair that shares t band signatures
+// sits in t runs; it is taken from the run of its FIRST matching band only (the bands before it are re-checked on the
+// query-major copy), so no de-duplication pass is needed.  Candidates are then verified with the literal smh_a exactly
+// as in ALGO_SIG: same candidate set, same survivor set.  Cost O(N*NB log) + output instead of O(N^2 * NB).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock)
+void sigkey_build_kernel(const uint32_t* __restrict__ sigT, int n, int n_pad, int nb,
+                         u64* __restrict__ keys, int* __restrict__ vals) {
+    const long long t = (long long)blockIdx.x * kBlock + threadIdx.x;
+    if (t >= (long long)n * nb) return;
+    const int b = (int)(t / n), g = (int)(t % n);
+    keys[t] = ((u64)b << 32) | sigT[(long long)b * n_pad + g];
+    vals[t] = g;
+}
+
+__global__ __launch_bounds__(kBlock)
+void run_emit_kernel(const u64* __restrict__ keys, const int* __restrict__ vals, long long total,
+                     const uint32_t* __restrict__ sigQ, int nb, const u64* __restrict__ aux, int m, int n_rows, int n_bands,
+                     int n, const int* __restrict__ hi, const PassCounters* __restrict__ pc_in, int row_begin, int row_end,
+                     selhip_int2_t* __restrict__ surv, u64 surv_cap, PassCounters* __restrict__ pc) {
+    __shared__ selhip_int2_t app_lds[kWavesPerBlock * kAppendCap];
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
+    const int z0 = pc_in->z0p1 ? pc_in->z0p1 - 1 : n;
+    WaveAppender app;
+    app.init(app_lds, wave, surv, surv_cap, &pc->n_survivors);
+    int n_cand = 0;
+    for (long long base = (long long)blockIdx.x * kBlock; base < total; base += (long long)gridDim.x * kBlock) {
+        const long long p = base + threadIdx.x;
+        const bool live = p < total;
+        const u64 key = live ? keys[p] : 0;
+        const int g = live ? vals[p] : 0;
+        const int b = (int)(key >> 32);
+        for (long long step = 1;; ++step) {                       // walk the run of equal keys that starts after p
+            const bool act = live && p + step < total && keys[p + step] == key;
+            if (!__any(act)) break;
+            bool cand = false;
+            int i = 0, k = 0;
+            if (act) {
+                const int g2 = vals[p + step];
+                i = min(g, g2); k = max(g, g2);
+                cand = i != k && i >= row_begin && i < row_end && k >= max(i + 1, z0) && k <= min(hi[i], n - 1);
+                if (cand) {                                        // take the pair from its first matching band only
+                    const uint32_t* qi = sigQ + (long long)i * nb;
+                    const uint32_t* qk = sigQ + (long long)k * nb;
+                    for (int bb = 0; bb < b && cand; ++bb) cand = qi[bb] != qk[bb];
+                }
+            }
+            n_cand += (int)__popcll(__ballot(cand));
+            const bool ok = cand && smh_a_lane(aux + (long long)i * m, aux + (long long)k * m, n_rows, n_bands);
+            app.push(ok, i, k, lane);
+        }
+    }
+    app.flush(lane);
+    if (lane == 0 && n_cand) atomicAdd(&pc->n_candidates, (u64)n_cand);
+}
+
 }  // namespace

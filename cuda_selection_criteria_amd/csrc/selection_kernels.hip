@@ -18,6 +18,7 @@
 //
 // Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off (see csrc/Makefile).
 #include <hip/hip_runtime.h>
+#include <rocprim/device/device_radix_sort.hpp>   // ALGO_HASHJOIN only: the key sort is a library call, everything else is hand-written
 
 #include <algorithm>
 #include <array>
@@ -127,6 +128,9 @@ struct selhip_ctx {
     int p_aux = 0;
     int criterion = 0;
     DevBuf<uint32_t> sigQ, sigT;        // ALGO_SIG: band signatures, query-major / band-major
+    DevBuf<u64> hj_keys_in, hj_keys_out;   // ALGO_HASHJOIN: (band << 32 | signature) keys, before / after the sort
+    DevBuf<int> hj_vals_in, hj_vals_out;   //                genome ranks carried by the keys
+    DevBuf<char> hj_tmp;                   //                rocPRIM temporary storage
     PassCounters* h_pc = nullptr;       // pinned host mirror of the kMaxChunks + 1 counter blocks
     // stage pipeline: stage 1 of row chunk c+1 (VALU-bound) overlaps stage 2 of chunk c (memory/LDS-bound)
     hipStream_t st_stage1 = nullptr, st_stage2 = nullptr;     // internal non-blocking streams
@@ -267,6 +271,8 @@ hipError_t launch_stage1(selhip_ctx* c, const StageIO& io, int n_rows, int n_ban
 }
 
 
+unsigned grid_for(u64 items, unsigned per_block, unsigned max_blocks);
+
 bool sig_supported(int m, int n_rows, int n_bands) {
     (void)m;
     return is_pow2(n_rows) && (n_bands == 8 || n_bands == 16 || n_bands == 32 || n_bands == 64 || n_bands == 128);
@@ -319,6 +325,28 @@ hipError_t launch_stage1_sig(selhip_ctx* c, const StageIO& io, int n_rows, int n
     TimerScope t(c, T_VERIFY, io.st);
     hipLaunchKernelGGL(verify_kernel, dim3(1024), dim3(kBlock), 0, io.st, c->d_aux, c->m, n_rows, n_bands,
                        io.cand, &io.pc->n_candidates, io.cap, io.surv, io.cap, io.pc);
+    return hipGetLastError();
+}
+
+// sort-based join of the band signatures (sig_build must have run); rows [rb, re)
+hipError_t launch_stage1_hashjoin(selhip_ctx* c, const StageIO& io, int n_rows, int n_bands, int rb, int re) {
+    const int n = (int)c->n;
+    const int n_pad = ((n + kWave - 1) / kWave) * kWave;
+    const long long total = (long long)n * n_bands;
+    if (total <= 0) return hipSuccess;
+    TimerScope t(c, T_JOIN, io.st);
+    hipLaunchKernelGGL(sigkey_build_kernel, dim3((unsigned)((total + kBlock - 1) / kBlock)), dim3(kBlock), 0, io.st,
+                       c->sigT.p, n, n_pad, n_bands, c->hj_keys_in.p, c->hj_vals_in.p);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    size_t tmp_bytes = c->hj_tmp.cap;
+    const unsigned end_bit = 32u + (unsigned)ilog2(n_bands) + 1u;
+    e = rocprim::radix_sort_pairs(c->hj_tmp.p, tmp_bytes, c->hj_keys_in.p, c->hj_keys_out.p, c->hj_vals_in.p, c->hj_vals_out.p,
+                                  (size_t)total, 0u, end_bit, io.st);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(run_emit_kernel, dim3(grid_for((u64)total, kBlock, 8192)), dim3(kBlock), 0, io.st,
+                       c->hj_keys_out.p, c->hj_vals_out.p, total, c->sigQ.p, n_bands, c->d_aux, c->m, n_rows, n_bands,
+                       n, c->hi.p, c->pc.p, rb, re, io.surv, io.cap, io.pc);
     return hipGetLastError();
 }
 
@@ -435,10 +463,16 @@ int enqueue_pass(selhip_ctx* c) {
                            c->d_cards, n, tau, c->mode == SELHIP_MODE_CB_SMH ? 1 : 0, rb, re, c->ecard.p, c->hi.p, pc0);
         HIPCHK(&c->err, hipGetLastError());
     }
-    const bool use_sig = (crit == SELHIP_CRIT_SMH_A || crit == SELHIP_CRIT_HLL_A_SMH_A) &&
-                         (c->algo == SELHIP_ALGO_SIG || c->algo == SELHIP_ALGO_AUTO) && sig_supported(c->m, c->n_rows, c->n_bands);
-    if ((crit == SELHIP_CRIT_SMH_A || crit == SELHIP_CRIT_HLL_A_SMH_A) && c->algo == SELHIP_ALGO_SIG && !use_sig) {
+    const bool smh_crit = crit == SELHIP_CRIT_SMH_A || crit == SELHIP_CRIT_HLL_A_SMH_A;
+    const bool use_hash = smh_crit && c->algo == SELHIP_ALGO_HASHJOIN;
+    const bool use_sig = use_hash || (smh_crit && (c->algo == SELHIP_ALGO_SIG || c->algo == SELHIP_ALGO_AUTO) &&
+                                      sig_supported(c->m, c->n_rows, c->n_bands));
+    if (smh_crit && c->algo == SELHIP_ALGO_SIG && !use_sig) {
         set_err(&c->err, "ALGO_SIG needs power-of-two rows and 8..128 bands (got %d x %d)", c->n_rows, c->n_bands);
+        return SELHIP_E_BADARG;
+    }
+    if (use_hash && (!is_pow2(c->n_rows) || c->n_bands > 65536)) {
+        set_err(&c->err, "ALGO_HASHJOIN needs power-of-two rows (got %d x %d)", c->n_rows, c->n_bands);
         return SELHIP_E_BADARG;
     }
     if (use_sig) HIPCHK(&c->err, launch_sig_build(c, c->n_rows, c->n_bands));
@@ -458,8 +492,9 @@ int enqueue_pass(selhip_ctx* c) {
             StageIO io{c->st_stage1, c->cand.p + (size_t)k * slice, c->surv.p + (size_t)k * slice, slice, pc0 + 1 + k};
             {
                 TimerScope t(c, T_STAGE1, io.st);
-                if (use_sig) HIPCHK(&c->err, launch_stage1_sig(c, io, c->n_rows, c->n_bands, (int)bnd[k], (int)bnd[k + 1]));
-                else         HIPCHK(&c->err, launch_stage1(c, io, c->n_rows, c->n_bands, (int)bnd[k], (int)bnd[k + 1]));
+                if (use_hash)     HIPCHK(&c->err, launch_stage1_hashjoin(c, io, c->n_rows, c->n_bands, (int)bnd[k], (int)bnd[k + 1]));
+                else if (use_sig) HIPCHK(&c->err, launch_stage1_sig(c, io, c->n_rows, c->n_bands, (int)bnd[k], (int)bnd[k + 1]));
+                else              HIPCHK(&c->err, launch_stage1(c, io, c->n_rows, c->n_bands, (int)bnd[k], (int)bnd[k + 1]));
             }
             HIPCHK(&c->err, hipEventRecord(c->ev_chunk[k], c->st_stage1));
             HIPCHK(&c->err, hipStreamWaitEvent(c->st_stage2, c->ev_chunk[k], 0));
@@ -489,8 +524,9 @@ int enqueue_pass(selhip_ctx* c) {
     u64 final_cap = (u64)c->surv.cap;
     if (crit == SELHIP_CRIT_SMH_A || crit == SELHIP_CRIT_HLL_A_SMH_A) {
         TimerScope t(c, T_STAGE1);
-        if (use_sig) HIPCHK(&c->err, launch_stage1_sig(c, io, c->n_rows, c->n_bands, rb, re));
-        else         HIPCHK(&c->err, launch_stage1(c, io, c->n_rows, c->n_bands, rb, re));
+        if (use_hash)     HIPCHK(&c->err, launch_stage1_hashjoin(c, io, c->n_rows, c->n_bands, rb, re));
+        else if (use_sig) HIPCHK(&c->err, launch_stage1_sig(c, io, c->n_rows, c->n_bands, rb, re));
+        else              HIPCHK(&c->err, launch_stage1(c, io, c->n_rows, c->n_bands, rb, re));
     } else {
         TimerScope t(c, T_STAGE1);
         const int rows = re - rb;
@@ -567,9 +603,19 @@ int ensure_scratch(selhip_ctx* c, size_t surv_cap, size_t res_cap) {
     {
         const size_t n_pad = (((size_t)c->n + kWave - 1) / kWave) * kWave;
         const size_t nb = (size_t)std::max(c->n_bands, 1);
-        if (nb <= 128) {
+        const bool hash = c->algo == SELHIP_ALGO_HASHJOIN;
+        if (nb <= 128 || hash) {
             HIPCHK(&c->err, c->sigQ.ensure((size_t)c->n * nb));
             HIPCHK(&c->err, c->sigT.ensure(n_pad * nb));
+        }
+        if (hash) {
+            const size_t total = (size_t)c->n * nb;
+            HIPCHK(&c->err, c->hj_keys_in.ensure(total)); HIPCHK(&c->err, c->hj_keys_out.ensure(total));
+            HIPCHK(&c->err, c->hj_vals_in.ensure(total)); HIPCHK(&c->err, c->hj_vals_out.ensure(total));
+            size_t tmp_bytes = 0;
+            HIPCHK(&c->err, rocprim::radix_sort_pairs(nullptr, tmp_bytes, c->hj_keys_in.p, c->hj_keys_out.p, c->hj_vals_in.p,
+                                                      c->hj_vals_out.p, total, 0u, 64u, c->stream));
+            HIPCHK(&c->err, c->hj_tmp.ensure(tmp_bytes + 256));
         }
     }
     // histogram scratch: 256 B per pair, at most 1 Mi pairs per window (256 MiB)
@@ -629,6 +675,7 @@ void selhip_ctx_destroy(selhip_ctx* c) {
     c->ecard.release(); c->hi.release(); c->pc.release(); c->surv.release();
     c->counts.release(); c->results.release(); c->self_pairs.release();
     c->cand.release(); c->sigQ.release(); c->sigT.release(); c->fin.release(); c->own_aux_hll.release();
+    c->hj_keys_in.release(); c->hj_keys_out.release(); c->hj_vals_in.release(); c->hj_vals_out.release(); c->hj_tmp.release();
     if (c->h_pc) (void)hipHostFree(c->h_pc);
     if (c->st_stage1) {
         (void)hipStreamDestroy(c->st_stage1); (void)hipStreamDestroy(c->st_stage2);
@@ -768,7 +815,7 @@ int selhip_ctx_run_async(selhip_ctx* c, int mode, int algo, float tau_f, int n_r
     if (!c) return SELHIP_E_BADARG;
     if (!c->d_aux && c->n) { set_err(&c->err, "run before upload/attach"); return SELHIP_E_STATE; }
     if (mode != SELHIP_MODE_SMH && mode != SELHIP_MODE_CB_SMH) { set_err(&c->err, "bad mode %d", mode); return SELHIP_E_BADARG; }
-    if (algo != SELHIP_ALGO_AUTO && algo != SELHIP_ALGO_STREAM && algo != SELHIP_ALGO_SIG) { set_err(&c->err, "bad algo %d", algo); return SELHIP_E_BADARG; }
+    if (algo != SELHIP_ALGO_AUTO && algo != SELHIP_ALGO_STREAM && algo != SELHIP_ALGO_SIG && algo != SELHIP_ALGO_HASHJOIN) { set_err(&c->err, "bad algo %d", algo); return SELHIP_E_BADARG; }
     if (c->criterion != SELHIP_CRIT_SMH_A && !c->d_aux_hll && c->n) {
         set_err(&c->err, "criterion %d needs auxiliary HLL sketches (selhip_ctx_upload_aux_hll)", c->criterion);
         return SELHIP_E_STATE;

@@ -55,6 +55,9 @@ typedef struct { int32_t i, k; double jaccard; } selhip_pair_t;
 #define SELHIP_ALGO_AUTO     0
 #define SELHIP_ALGO_STREAM   1     /* full m-bucket compare, candidates streamed row-major, query tile in LDS */
 #define SELHIP_ALGO_SIG      2     /* 32-bit band signatures joined all-pairs, exact verify of candidates  */
+#define SELHIP_ALGO_HASHJOIN 3     /* sub-quadratic: (band, signature) keys radix-sorted, candidates read off the runs of equal
+                                      keys, exact verify -- same survivors, but pairs are no longer compared one by one
+                                      (never chosen by AUTO; not what the pair-comparisons/s metric measures)          */
 
 /* selection criterion applied before the final HLL-14 Jaccard test (src/selection.cpp -c ...):
  *   SMH_A        src/selection.cpp:228-291   (the north_star path)

@@ -7,7 +7,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 import cuda_selection_criteria_amd as pkg  # noqa: E402
-from cuda_selection_criteria_amd import ALGO_SIG, ALGO_STREAM, MODE_CB_SMH, MODE_SMH, Selector  # noqa: E402
+from cuda_selection_criteria_amd import ALGO_HASHJOIN, ALGO_SIG, ALGO_STREAM, MODE_CB_SMH, MODE_SMH, Selector  # noqa: E402
 
 
 def fetch_np(hll_t, aux_t, cards_t):
@@ -31,7 +31,7 @@ def test_baseline_configs_bit_exact_vs_oracle(oracle, key):
         sel.attach(hll_t, aux_t, cards_t)
         for mode, use_cb in ((MODE_SMH, False), (MODE_CB_SMH, True)):
             want, st = oracle.select(hll, aux, cards, cfg.tau, r, b, use_cb=use_cb, threads=16)
-            for algo in (ALGO_SIG, ALGO_STREAM):
+            for algo in (ALGO_SIG, ALGO_STREAM, ALGO_HASHJOIN):
                 got = sel.run(cfg.tau, mode, r, b, algo=algo)
                 assert same(got, want), (key, mode, algo, len(got), len(want))
                 s = sel.stats()
@@ -73,6 +73,9 @@ def test_config4_scale_properties():
         a = sel.run(cfg.tau, MODE_SMH, r, b, rows=(lo, hi), algo=ALGO_STREAM)
         s = sel.run(cfg.tau, MODE_SMH, r, b, rows=(lo, hi), algo=ALGO_SIG)
         assert np.array_equal(a, s) and len(a) > 0
+        # the sort-based join returns the same result for the whole 1.25e9-pair space
+        hj = sel.run(cfg.tau, MODE_SMH, r, b, algo=ALGO_HASHJOIN)
+        assert np.array_equal(hj, whole)
 
 
 def test_config5_two_stage_properties(oracle):

@@ -13,7 +13,7 @@ from conftest import GOLDEN
 pytestmark = pytest.mark.gpu
 
 import cuda_selection_criteria_amd as pkg  # noqa: E402
-from cuda_selection_criteria_amd import (ALGO_AUTO, ALGO_SIG, ALGO_STREAM, FP_FMA, FP_STRICT, MODE_CB_SMH, MODE_SMH, Selector)  # noqa: E402
+from cuda_selection_criteria_amd import (ALGO_AUTO, ALGO_HASHJOIN, ALGO_SIG, ALGO_STREAM, FP_FMA, FP_STRICT, MODE_CB_SMH, MODE_SMH, Selector)  # noqa: E402
 from cuda_selection_criteria_amd.synth import SynthConfig  # noqa: E402
 
 sys.path.insert(0, str(GOLDEN))
@@ -60,7 +60,7 @@ def test_synthetic_vs_oracle_and_golden(oracle, name, fp_mode):
                 assert (r, b) == oracle.banding(cfg.m, tau)
                 for mode, use_cb in ((MODE_CB_SMH, True), (MODE_SMH, False)):
                     want, st = oracle.select(hll, aux, cards, tau, r, b, use_cb=use_cb)
-                    for algo in (ALGO_STREAM, ALGO_SIG, ALGO_AUTO):
+                    for algo in (ALGO_STREAM, ALGO_SIG, ALGO_AUTO, ALGO_HASHJOIN):
                         if algo == ALGO_SIG and b not in (8, 16, 32, 64, 128):
                             with pytest.raises(pkg.SelhipError):
                                 sel.run(tau, mode, r, b, algo=algo)
@@ -154,7 +154,7 @@ def test_row_shards_union_equals_whole(oracle):
     r, b = pkg.banding(cfg.m, cfg.tau)
     with Selector(0) as sel:
         sel.upload(hll, aux, cards)
-        for algo in (ALGO_STREAM, ALGO_SIG):
+        for algo in (ALGO_STREAM, ALGO_SIG, ALGO_HASHJOIN):
             whole = sel.run(cfg.tau, MODE_CB_SMH, r, b, algo=algo)
             parts = []
             bounds = [0, 137, 138, 500, 999, 1000]
@@ -223,7 +223,7 @@ def test_edge_cases(oracle):
         # all band shapes of m=128, including rows=1 and rows=m
         for rows in (1, 2, 4, 8, 16, 32, 64, 128):
             want, st = oracle.select(h3, a3, c3, 0.3, rows, 128 // rows, use_cb=False)
-            for algo in (ALGO_STREAM, ALGO_AUTO):
+            for algo in (ALGO_STREAM, ALGO_AUTO, ALGO_HASHJOIN):
                 got = sel.run(0.3, MODE_SMH, rows, 128 // rows, algo=algo)
                 assert_same_pairs(got, want)
                 assert sel.stats()["survivors"] == st["survivors"], rows

@@ -7,7 +7,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 import cuda_selection_criteria_amd as pkg  # noqa: E402
-from cuda_selection_criteria_amd import ALGO_AUTO, ALGO_SIG, ALGO_STREAM, MODE_CB_SMH, MODE_SMH, Selector  # noqa: E402
+from cuda_selection_criteria_amd import ALGO_AUTO, ALGO_HASHJOIN, ALGO_SIG, ALGO_STREAM, MODE_CB_SMH, MODE_SMH, Selector  # noqa: E402
 from cuda_selection_criteria_amd.synth import SynthConfig  # noqa: E402
 
 
@@ -50,6 +50,7 @@ def test_random_configuration(oracle, seed):
                     algos = [ALGO_AUTO]
                     if crit in (pkg.CRIT_SMH_A, pkg.CRIT_HLL_A_SMH_A):
                         algos.append(ALGO_STREAM)
+                        algos.append(ALGO_HASHJOIN)
                         if b in (8, 16, 32, 64, 128):
                             algos.append(ALGO_SIG)
                     for algo in algos:
