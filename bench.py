@@ -42,6 +42,7 @@ def parse():
     ap.add_argument("--algo", choices=["auto", "stream", "sig", "hashjoin"], default="auto",
                     help="hashjoin = sub-quadratic sort-based candidate generation: NOT the brute-force pair-comparison metric")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-grouping", action="store_true", help="stage 2 without bucketing the survivors by query row")
     ap.add_argument("--pipeline", type=int, default=-1, help="-1 auto, 0 off, 2..8 row chunks (stage 1 of chunk c+1 overlaps stage 2 of chunk c)")
     ap.add_argument("--pcie", action="store_true", help="also time a PCIe-inclusive pass (host buffers -> upload -> run)")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
@@ -95,6 +96,7 @@ def main():
     sel = pkg.Selector(local_rank)
     sel.attach(hll_t, aux_t, cards_t)
     sel.set_pipeline(args.pipeline)
+    sel.set_stage2_grouping(not args.no_grouping)
     two_stage = cfg.p_aux > 0                      # BASELINE configs[4]: hll_a prefilter + smh_a
     if two_stage:
         sel.attach_aux_hll(aux_hll_t, cfg.p_aux)
@@ -216,7 +218,7 @@ def main():
                 traffic = None
         hist_ms = sel.kernel_ms("hist")
         surv0 = st["survivors"]
-        kernels = {k: sel.kernel_ms(k) for k in ("prep", "sigbuild", "join", "verify", "stage1", "aux", "hist", "select", "total")
+        kernels = {k: sel.kernel_ms(k) for k in ("prep", "sigbuild", "join", "verify", "stage1", "aux", "group", "hist", "select", "total")
                    if sel.kernel_ms(k) > 0}
         out = {
             "metric": "sketch pair-comparisons/sec (N genomes x m buckets)",

@@ -104,6 +104,84 @@ void hll_union_hist_kernel(const uint8_t* __restrict__ hll, int p,
 }
 
 // ---------------------------------------------------------------------------------------------
+// Grouping survivors by query row, and the histogram kernel that exploits it.  Stage 2a is bound by the bytes it
+// pulls through the memory system (32 KiB per pair; PMC: LDS array 30 % busy, VALU 48 %), and a query row with g
+// survivors is read g times.  csr_count / csr_fill bucket the pair list by its first rank (counting sort, order inside
+// a bucket free), and hll_union_hist_runs_kernel lets each wave walk kRunLen consecutive pairs of the grouped list with
+// row x held in registers for as long as x does not change: (g + 1) instead of 2g row reads per group.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock)
+void csr_count_kernel(const selhip_int2_t* __restrict__ pairs, const u64* __restrict__ n_dev, u64 cap, int* __restrict__ cnt) {
+    u64 n = *n_dev;
+    if (n > cap) n = cap;
+    for (u64 j = (u64)blockIdx.x * kBlock + threadIdx.x; j < n; j += (u64)gridDim.x * kBlock) atomicAdd(&cnt[pairs[j].x], 1);
+}
+
+__global__ __launch_bounds__(kBlock)
+void csr_fill_kernel(const selhip_int2_t* __restrict__ pairs, const u64* __restrict__ n_dev, u64 cap,
+                     const int* __restrict__ start, int* __restrict__ fill, selhip_int2_t* __restrict__ grouped) {
+    u64 n = *n_dev;
+    if (n > cap) n = cap;
+    for (u64 j = (u64)blockIdx.x * kBlock + threadIdx.x; j < n; j += (u64)gridDim.x * kBlock) {
+        const selhip_int2_t pr = pairs[j];
+        grouped[start[pr.x] + atomicAdd(&fill[pr.x], 1)] = pr;
+    }
+}
+
+constexpr int kRunLen = 8;
+
+__global__ __launch_bounds__(kBlock)
+void hll_union_hist_runs_kernel(const uint8_t* __restrict__ hll, const selhip_int2_t* __restrict__ pairs,
+                                const u64* __restrict__ n_pairs_dev, u64 cap, uint32_t* __restrict__ counts,
+                                u64 chunk_off, u64 chunk_len) {
+    __shared__ uint32_t hist[kWavesPerBlock][64 * kWave];     // 64 KiB, one lane-private histogram per wave
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
+    u64 n_pairs = *n_pairs_dev;
+    if (n_pairs > cap) n_pairs = cap;
+    n_pairs = n_pairs > chunk_off ? min(n_pairs - chunk_off, chunk_len) : 0;
+    pairs += chunk_off;
+    uint32_t* my = hist[wave];
+    uint32_t* col = my + lane;
+    const u64 n_tasks = (n_pairs + kRunLen - 1) / kRunLen;
+    for (u64 task = (u64)blockIdx.x * kWavesPerBlock + wave; task < n_tasks; task += (u64)gridDim.x * kWavesPerBlock) {
+        const u64 j0 = task * kRunLen, j1 = min(j0 + kRunLen, n_pairs);
+        int cur_x = -1;
+        uint4 xa[16];
+        for (u64 j = j0; j < j1; ++j) {
+            const selhip_int2_t pr = pairs[j];
+            const uint4* b4 = reinterpret_cast<const uint4*>(hll + (long long)pr.y * 16384);
+            uint4 xb[16];
+#pragma unroll
+            for (int it = 0; it < 16; ++it) xb[it] = b4[it * kWave + lane];
+            if (pr.x != cur_x) {                                  // wave-uniform: the row of the group leader changes
+                const uint4* a4 = reinterpret_cast<const uint4*>(hll + (long long)pr.x * 16384);
+#pragma unroll
+                for (int it = 0; it < 16; ++it) xa[it] = a4[it * kWave + lane];
+                cur_x = pr.x;
+            }
+#pragma unroll 8
+            for (int b = 0; b < 64; ++b) col[b * kWave] = 0;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+#pragma unroll
+            for (int it = 0; it < 16; ++it) {
+                hist_add_word(col, max_u8x4(xa[it].x, xb[it].x));
+                hist_add_word(col, max_u8x4(xa[it].y, xb[it].y));
+                hist_add_word(col, max_u8x4(xa[it].z, xb[it].z));
+                hist_add_word(col, max_u8x4(xa[it].w, xb[it].w));
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            uint32_t sacc = 0;
+            const uint32_t* rowp = my + lane * kWave;
+#pragma unroll 8
+            for (int t = 0; t < kWave; ++t) sacc += rowp[(t + lane) & (kWave - 1)];
+            counts[j * 64 + lane] = sacc;
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // ertl_select_kernel: one LANE per histogram.  The 64 histograms of a wave are staged in LDS
 // (pitch 65 -> conflict-free) because the estimator indexes them with run-time k.
 //   MODE 0: est[j] = estimate                                     (selhip_ertl_estimate, cards)

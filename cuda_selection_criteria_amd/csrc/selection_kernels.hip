@@ -18,6 +18,7 @@
 //
 // Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off (see csrc/Makefile).
 #include <hip/hip_runtime.h>
+#include <rocprim/device/device_scan.hpp>         // exclusive scan of the per-row survivor counts (grouping for stage 2)
 #include <rocprim/device/device_radix_sort.hpp>   // ALGO_HASHJOIN only: the key sort is a library call, everything else is hand-written
 
 #include <algorithm>
@@ -91,8 +92,8 @@ struct KernelTimer {
 
 constexpr int kMaxChunks = 8;
 
-enum { T_PREP = 0, T_STAGE1, T_HIST, T_SELECT, T_TOTAL, T_SIGBUILD, T_JOIN, T_VERIFY, T_AUX, T_COUNT };
-const char* kTimerNames[T_COUNT] = {"prep", "stage1", "hist", "select", "total", "sigbuild", "join", "verify", "aux"};
+enum { T_PREP = 0, T_STAGE1, T_HIST, T_SELECT, T_TOTAL, T_SIGBUILD, T_JOIN, T_VERIFY, T_AUX, T_GROUP, T_COUNT };
+const char* kTimerNames[T_COUNT] = {"prep", "stage1", "hist", "select", "total", "sigbuild", "join", "verify", "aux", "group"};
 
 }  // namespace
 
@@ -131,12 +132,16 @@ struct selhip_ctx {
     DevBuf<u64> hj_keys_in, hj_keys_out;   // ALGO_HASHJOIN: (band << 32 | signature) keys, before / after the sort
     DevBuf<int> hj_vals_in, hj_vals_out;   //                genome ranks carried by the keys
     DevBuf<char> hj_tmp;                   //                rocPRIM temporary storage
+    DevBuf<int> csr_cnt, csr_start;        // stage 2 grouping: survivors per query row (cnt[0..n) counts, cnt[n..2n) fill cursors), offsets
+    DevBuf<selhip_int2_t> grouped;         //                   the final pair list bucketed by query row
+    DevBuf<char> scan_tmp;
     PassCounters* h_pc = nullptr;       // pinned host mirror of the kMaxChunks + 1 counter blocks
     // stage pipeline: stage 1 of row chunk c+1 (VALU-bound) overlaps stage 2 of chunk c (memory/LDS-bound)
     hipStream_t st_stage1 = nullptr, st_stage2 = nullptr;     // internal non-blocking streams
     hipEvent_t ev_start = nullptr, ev_end = nullptr, ev_chunk[8] = {};
     int n_chunks_last = 1;
     int pipeline = -1;                  // -1 auto, 0 off, >0 forced chunk count
+    bool group_stage2 = true;           // bucket survivors by query row before stage 2a (hll_union_hist_runs_kernel)
 
     // last run parameters (for overflow re-runs)
     bool have_run = false, pending = false;
@@ -560,11 +565,30 @@ int enqueue_pass(selhip_ctx* c) {
     // ---- final criterion: HLL-14 union estimate + Jaccard (selection.cpp:286-288), windows of the counts buffer
     {
         const u64 window = (u64)c->counts.cap / 64;
+        const bool grouped = c->p == 14 && c->group_stage2;
+        if (grouped) {
+            // bucket the final list by query row so that stage 2a can keep that row in registers across its pairs
+            TimerScope t(c, T_GROUP);
+            HIPCHK(&c->err, hipMemsetAsync(c->csr_cnt.p, 0, sizeof(int) * 2 * (size_t)n, c->stream));
+            hipLaunchKernelGGL(csr_count_kernel, dim3(512), dim3(kBlock), 0, c->stream, final_list, final_count, final_cap, c->csr_cnt.p);
+            HIPCHK(&c->err, hipGetLastError());
+            size_t tmp_bytes = c->scan_tmp.cap;
+            HIPCHK(&c->err, rocprim::exclusive_scan(c->scan_tmp.p, tmp_bytes, c->csr_cnt.p, c->csr_start.p, 0, (size_t)n,
+                                                    rocprim::plus<int>(), c->stream));
+            hipLaunchKernelGGL(csr_fill_kernel, dim3(512), dim3(kBlock), 0, c->stream, final_list, final_count, final_cap,
+                               c->csr_start.p, c->csr_cnt.p + n, c->grouped.p);
+            HIPCHK(&c->err, hipGetLastError());
+            final_list = c->grouped.p;
+        }
         for (u64 off = 0; off < final_cap; off += window) {
             {
                 TimerScope t(c, T_HIST);
-                hipLaunchKernelGGL(hll_union_hist_kernel, dim3(2048), dim3(kBlock), 0, c->stream,
-                                   c->d_hll, c->p, final_list, final_count, (u64)0, final_cap, c->counts.p, off, window);
+                if (grouped)
+                    hipLaunchKernelGGL(hll_union_hist_runs_kernel, dim3(2048), dim3(kBlock), 0, c->stream,
+                                       c->d_hll, final_list, final_count, final_cap, c->counts.p, off, window);
+                else
+                    hipLaunchKernelGGL(hll_union_hist_kernel, dim3(2048), dim3(kBlock), 0, c->stream,
+                                       c->d_hll, c->p, final_list, final_count, (u64)0, final_cap, c->counts.p, off, window);
                 HIPCHK(&c->err, hipGetLastError());
             }
             TimerScope t(c, T_SELECT);
@@ -621,6 +645,14 @@ int ensure_scratch(selhip_ctx* c, size_t surv_cap, size_t res_cap) {
     // histogram scratch: 256 B per pair, at most 1 Mi pairs per window (256 MiB)
     HIPCHK(&c->err, c->counts.ensure(std::min<size_t>(std::max(c->surv.cap, (size_t)c->n), (size_t)1 << 20) * 64));
     HIPCHK(&c->err, c->results.ensure(res_cap));
+    if (c->group_stage2 && c->p == 14) {
+        HIPCHK(&c->err, c->csr_cnt.ensure(2 * (size_t)c->n + 2));
+        HIPCHK(&c->err, c->csr_start.ensure((size_t)c->n + 2));
+        HIPCHK(&c->err, c->grouped.ensure(surv_cap));
+        size_t tmp_bytes = 0;
+        HIPCHK(&c->err, rocprim::exclusive_scan(nullptr, tmp_bytes, c->csr_cnt.p, c->csr_start.p, 0, (size_t)c->n, rocprim::plus<int>(), c->stream));
+        HIPCHK(&c->err, c->scan_tmp.ensure(tmp_bytes + 256));
+    }
     if (!c->h_pc) HIPCHK(&c->err, hipHostMalloc((void**)&c->h_pc, sizeof(PassCounters) * (kMaxChunks + 1), hipHostMallocDefault));
     return SELHIP_OK;
 }
@@ -676,6 +708,7 @@ void selhip_ctx_destroy(selhip_ctx* c) {
     c->counts.release(); c->results.release(); c->self_pairs.release();
     c->cand.release(); c->sigQ.release(); c->sigT.release(); c->fin.release(); c->own_aux_hll.release();
     c->hj_keys_in.release(); c->hj_keys_out.release(); c->hj_vals_in.release(); c->hj_vals_out.release(); c->hj_tmp.release();
+    c->csr_cnt.release(); c->csr_start.release(); c->grouped.release(); c->scan_tmp.release();
     if (c->h_pc) (void)hipHostFree(c->h_pc);
     if (c->st_stage1) {
         (void)hipStreamDestroy(c->st_stage1); (void)hipStreamDestroy(c->st_stage2);
@@ -694,6 +727,12 @@ int selhip_ctx_set_stream(selhip_ctx* c, void* hip_stream) {
 int selhip_ctx_set_fp_mode(selhip_ctx* c, int fp_mode) {
     if (!c || (fp_mode != SELHIP_FP_FMA && fp_mode != SELHIP_FP_STRICT)) return SELHIP_E_BADARG;
     c->fp_mode = fp_mode;
+    return SELHIP_OK;
+}
+
+int selhip_ctx_set_stage2_grouping(selhip_ctx* c, int enable) {
+    if (!c) return SELHIP_E_BADARG;
+    c->group_stage2 = enable != 0;
     return SELHIP_OK;
 }
 

@@ -115,6 +115,9 @@ int selhip_ctx_set_stream(selhip_ctx* ctx, void* hip_stream);
  * of chunk c+1 runs on one internal stream while stage 2 (HLL union histograms, memory/LDS-bound) of chunk c runs on
  * another.  -1 / 0 / 1 = off (the default: measured slower or equal on MI355X), 2..8 = chunk count. */
 int selhip_ctx_set_pipeline(selhip_ctx* ctx, int chunks);
+/* Stage 2 grouping (default on): the pairs that reach the HLL-14 stage are bucketed by query row (counting sort) so
+ * that the histogram kernel reads a query row once per group instead of once per pair.  0 = off (ungrouped kernel). */
+int selhip_ctx_set_stage2_grouping(selhip_ctx* ctx, int enable);
 /* SELHIP_FP_FMA (default) or SELHIP_FP_STRICT */
 int selhip_ctx_set_fp_mode(selhip_ctx* ctx, int fp_mode);
 
@@ -173,7 +176,7 @@ int selhip_ctx_copy_results_framed(selhip_ctx* ctx, void* d_dst, int64_t cap_rec
 
 /* device time (ms, HIP events on the stream each kernel is launched on) of the named kernel PER PASS, averaged over
  * the passes since the last reset (a pipelined pass launches a kernel once per row chunk: the figure is their sum);
- * names: "prep", "sigbuild", "join", "verify", "stage1", "aux", "hist", "select", "total".  <0 if never launched.
+ * names: "prep", "sigbuild", "join", "verify", "stage1", "aux", "group", "hist", "select", "total".  <0 if never launched.
  * selhip_ctx_kernel_launches: launches of that kernel per pass. */
 double selhip_ctx_kernel_ms(const selhip_ctx* ctx, const char* name);
 double selhip_ctx_kernel_launches(const selhip_ctx* ctx, const char* name);

@@ -185,6 +185,20 @@ def test_pipelined_pass_equals_plain(oracle):
                         assert s["survivors"] == st["survivors"] and s["evaluated"] == st["evaluated"]
 
 
+def test_stage2_grouping_on_off(oracle):
+    """survivors bucketed by query row (run-aware histogram kernel) vs the ungrouped kernel: identical results"""
+    cfg = make_golden.GOLDEN_SYNTH["synth_spread_n600_m64"]
+    hll, aux, cards, _, _ = sorted_set(cfg, oracle)
+    r, b = pkg.banding(cfg.m, 0.5)
+    want, _ = oracle.select(hll, aux, cards, 0.5, r, b)
+    with Selector(0) as sel:
+        sel.upload(hll, aux, cards)
+        for on in (True, False, True):
+            sel.set_stage2_grouping(on)
+            assert_same_pairs(sel.run(0.5, MODE_CB_SMH, r, b), want)
+            assert_same_pairs(sel.run(0.5, MODE_CB_SMH, r, b, rows=(17, 333)), want[(want["i"] >= 17) & (want["i"] < 333)])
+
+
 def test_edge_cases(oracle):
     cfg = SynthConfig("edge", 130, 128, 0.9, 77, n_sh_lo=5000, n_sh_hi=5000)
     hll, aux, cards, _, _ = sorted_set(cfg, oracle)
