@@ -141,6 +141,7 @@ struct selhip_ctx {
     hipEvent_t ev_start = nullptr, ev_end = nullptr, ev_chunk[8] = {};
     int n_chunks_last = 1;
     int pipeline = -1;                  // -1 auto, 0 off, >0 forced chunk count
+    int join_qt = 96;                   // query rows per signature-join block (multiple of 16); measured flat 48..192
     bool group_stage2 = true;           // bucket survivors by query row before stage 2a (hll_union_hist_runs_kernel)
 
     // last run parameters (for overflow re-runs)
@@ -286,7 +287,7 @@ bool sig_supported(int m, int n_rows, int n_bands) {
 template <int NB>
 hipError_t launch_join(selhip_ctx* c, const StageIO& io, int n_pad, int rb, int re) {
     const int n = (int)c->n;
-    const int qt = 128;                 // query rows per block (multiple of 16); 32..128 measured equal, 256+ slower
+    const int qt = c->join_qt;          // query rows per block (multiple of 16)
     const int n_tiles = (re - rb + qt - 1) / qt;
     const int group_base = ((rb + 1) / kWave / kWavesPerBlock) * kWavesPerBlock;      // candidates k > row_begin
     const int n_groups = (n + kWave - 1) / kWave - group_base;
@@ -728,6 +729,17 @@ int selhip_ctx_set_fp_mode(selhip_ctx* c, int fp_mode) {
     if (!c || (fp_mode != SELHIP_FP_FMA && fp_mode != SELHIP_FP_STRICT)) return SELHIP_E_BADARG;
     c->fp_mode = fp_mode;
     return SELHIP_OK;
+}
+
+int selhip_ctx_set_param(selhip_ctx* c, const char* name, int value) {
+    if (!c || !name) return SELHIP_E_BADARG;
+    if (!std::strcmp(name, "join_qt")) {
+        if (value < 16 || value > 4096 || value % 16) { set_err(&c->err, "join_qt must be a multiple of 16 in [16, 4096]"); return SELHIP_E_BADARG; }
+        c->join_qt = value;
+        return SELHIP_OK;
+    }
+    set_err(&c->err, "unknown parameter '%s'", name);
+    return SELHIP_E_BADARG;
 }
 
 int selhip_ctx_set_stage2_grouping(selhip_ctx* c, int enable) {

@@ -157,6 +157,9 @@ class Selector:
         """-1 auto, 0 off, 2..8 forced: overlap of stage 1 (next row chunk) with stage 2 (previous chunk)"""
         check(self._lib.selhip_ctx_set_pipeline(self._ctx, chunks), self._ctx)
 
+    def set_param(self, name: str, value: int):
+        check(self._lib.selhip_ctx_set_param(self._ctx, name.encode(), value), self._ctx)
+
     def set_stage2_grouping(self, enable: bool):
         check(self._lib.selhip_ctx_set_stage2_grouping(self._ctx, 1 if enable else 0), self._ctx)
 

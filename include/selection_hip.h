@@ -115,6 +115,8 @@ int selhip_ctx_set_stream(selhip_ctx* ctx, void* hip_stream);
  * of chunk c+1 runs on one internal stream while stage 2 (HLL union histograms, memory/LDS-bound) of chunk c runs on
  * another.  -1 / 0 / 1 = off (the default: measured slower or equal on MI355X), 2..8 = chunk count. */
 int selhip_ctx_set_pipeline(selhip_ctx* ctx, int chunks);
+/* Tunables (integers by name): "join_qt" = query rows per block of the signature join (multiple of 16, default 96). */
+int selhip_ctx_set_param(selhip_ctx* ctx, const char* name, int value);
 /* Stage 2 grouping (default on): the pairs that reach the HLL-14 stage are bucketed by query row (counting sort) so
  * that the histogram kernel reads a query row once per group instead of once per pair.  0 = off (ungrouped kernel). */
 int selhip_ctx_set_stage2_grouping(selhip_ctx* ctx, int enable);
