@@ -255,6 +255,32 @@ def main():
                                        "frac": valu / (dom_ms * 1e-3) / (256 * 4 * 2.4e9 / 4),
                                        "note": "peak = 1024 SIMDs x 2.4 GHz / 4 cycles per wave64 VALU instruction"}
 
+    # ---- the literal north_star kernel (ALGO_STREAM: query tile staged in LDS, candidates streamed row-major, lane-mask
+    # reduction) measured beside the default algorithm, outside the timed region (rank 0, N=1, same inputs)
+    if rank == 0 and world == 1 and args.algo == "auto" and not two_stage:
+        for _ in range(2):
+            sel.run(cfg.tau, mode, n_rows, n_bands, algo=pkg.ALGO_STREAM, fetch=False)
+        sel.timing(True)
+        t0s = time.perf_counter()
+        ks = 5
+        for _ in range(ks):
+            sel.run(cfg.tau, mode, n_rows, n_bands, algo=pkg.ALGO_STREAM, fetch=False)
+        torch.cuda.synchronize(dev)
+        dts = (time.perf_counter() - t0s) / ks
+        s_ms = sel.kernel_ms("stage1")
+        s_st = sel.stats()
+        s_bytes = s_st["evaluated"] * 8 * cfg.m
+        s_traffic = None
+        try:
+            s_traffic = json.loads((ROOT / "profiles" / "stage1_traffic.json").read_text()).get(f"{args.workload}:stream")
+        except Exception:
+            pass
+        out["stream_kernel"] = {"algo": "stream", "pairs_per_s": s_st["evaluated"] / dts, "ms_per_step": dts * 1e3, "selected_pairs": s_st["selected"],
+                                "roofline": {"bound": "hbm", "kernel": "smh_stream_kernel", "achieved": s_bytes / (s_ms * 1e-3) / 1e9,
+                                             "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": s_bytes / (s_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                             "traffic": s_traffic, "avg_launch_ms": s_ms, "algorithmic_bytes_per_launch": s_bytes}}
+        sel.timing(False)
+
     # ---- CPU baseline: the oracle (OpenMP port of selection.cpp:270-291 / time_smh.cpp:229-257) on a bounded sample
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         sys.path.insert(0, str(ROOT / "tests"))
