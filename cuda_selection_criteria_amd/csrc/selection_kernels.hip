@@ -23,6 +23,7 @@
 
 #include <algorithm>
 #include <array>
+#include <chrono>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -453,6 +454,18 @@ int pipeline_chunks(const selhip_ctx* c) {
     // So the automatic setting is OFF; the mechanism stays for workloads with a heavier memory-bound stage 2.
     if (c->pipeline <= 1) return 1;
     return std::min(c->pipeline, kMaxChunks);
+}
+
+// Wait for the context's stream with low wake-up latency: poll for up to ~2 ms (a pass of the BASELINE single-GPU
+// configurations takes 0.5-20 ms and the blocking wait's wake-up costs tens of microseconds), then block.
+hipError_t wait_stream(hipStream_t st) {
+    const auto t0 = std::chrono::steady_clock::now();
+    for (;;) {
+        const hipError_t e = hipStreamQuery(st);
+        if (e != hipErrorNotReady) return e;
+        if (std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) break;
+    }
+    return hipStreamSynchronize(st);
 }
 
 int enqueue_pass(selhip_ctx* c) {
@@ -899,7 +912,7 @@ int selhip_ctx_finish(selhip_ctx* c) {
     if (!c->pending) return c->have_run ? SELHIP_OK : SELHIP_E_STATE;
     HIPCHK(&c->err, hipSetDevice(c->device));
     for (int attempt = 0; attempt < 8; ++attempt) {
-        HIPCHK(&c->err, hipStreamSynchronize(c->stream));
+        HIPCHK(&c->err, wait_stream(c->stream));
         // block 0 = pass-wide counters; blocks 1..chunks = per-row-chunk list counters (each list slice = cap / chunks)
         PassCounters pc = c->h_pc[0];
         const int chunks = c->n_chunks_last;
