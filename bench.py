@@ -33,8 +33,8 @@ HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md, ch
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="cfg3", help="key of cuda_selection_criteria_amd.synth.SYNTH_CONFIGS")
     ap.add_argument("--genomes", type=int, default=0, help="override the genome count (0 = config value, scaled by sqrt(gpus))")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
