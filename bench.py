@@ -45,6 +45,7 @@ def parse():
     ap.add_argument("--no-grouping", action="store_true", help="stage 2 without bucketing the survivors by query row")
     ap.add_argument("--pipeline", type=int, default=-1, help="-1 auto, 0 off, 2..8 row chunks (stage 1 of chunk c+1 overlaps stage 2 of chunk c)")
     ap.add_argument("--pcie", action="store_true", help="also time a PCIe-inclusive pass (host buffers -> upload -> run)")
+    ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed and run the collectives even with one rank (RCCL smoke test)")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
                     help="gloo = rehearsal of the multi-rank logic on a box with fewer GPUs than ranks (records staged through the host)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the baseline sample")
@@ -73,8 +74,16 @@ def main():
     local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    dist_on = world > 1 or args.force_dist
+    if dist_on:
+        # stdout carries exactly one JSON line.  NCCL_DEBUG=VERSION (set on this pool) makes RCCL printf a five-line banner
+        # to stdout at init; that level logs nothing else, so it is dropped here -- any other level the user set is kept,
+        # with its output sent to a file.
+        if os.environ.get("NCCL_DEBUG", "").upper() == "VERSION":
+            del os.environ["NCCL_DEBUG"]
+        os.environ.setdefault("NCCL_DEBUG_FILE", "/tmp/rccl_debug.%h.%p.log")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29555")
         if args.backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
@@ -131,12 +140,12 @@ def main():
 
     def size_gather(local_count):
         mx = torch.tensor([local_count], dtype=torch.int64, device=cdev)
-        if world > 1:
+        if dist_on:
             dist.all_reduce(mx, op=dist.ReduceOp.MAX)
         cap = (int(mx.item()) * 5 // 4 + 4096) // 4096 * 4096
         state["cap"] = cap
         state["send"] = torch.zeros((cap + 1, 2), dtype=torch.int64, device=dev)              # 16 B records
-        state["recv"] = torch.zeros((world, cap + 1, 2), dtype=torch.int64, device=cdev) if world > 1 else None
+        state["recv"] = torch.zeros((world, cap + 1, 2), dtype=torch.int64, device=cdev) if dist_on else None
         state["host"] = torch.zeros((cap + 1, 2), dtype=torch.int64).pin_memory() if args.backend == "gloo" else None
 
     def step():
@@ -146,7 +155,7 @@ def main():
             size_gather(cnt)
         send = state["send"]
         sel.copy_results_framed(send)                       # header {count} + records, device-to-device, no host hop
-        if world > 1:
+        if dist_on:
             if args.backend == "nccl":
                 dist.all_gather_into_tensor(state["recv"].view(-1), send.view(-1))            # RCCL over xGMI
             else:
@@ -156,7 +165,7 @@ def main():
 
     def sync_all():
         torch.cuda.synchronize(dev)
-        if world > 1:
+        if dist_on:
             dist.barrier()
             torch.cuda.synchronize(dev)
 
@@ -176,7 +185,7 @@ def main():
     t_max = torch.tensor([dt], dtype=torch.float64, device=cdev)
     totals = torch.tensor([st["evaluated"], st["survivors"], st["selected"]], dtype=torch.int64, device=cdev)
     s1 = torch.tensor([stage1_ms], dtype=torch.float64, device=cdev)
-    if world > 1:
+    if dist_on:
         dist.all_reduce(t_max, op=dist.ReduceOp.MAX)
         dist.all_reduce(totals, op=dist.ReduceOp.SUM)
         dist.all_reduce(s1, op=dist.ReduceOp.MAX)
@@ -185,7 +194,7 @@ def main():
     value = pairs_per_step * args.steps / dt
 
     # ---- result check outside the timed region: the gathered list holds every rank's records -------------------
-    if world > 1:
+    if dist_on:
         rec = state["recv"].cpu().numpy()
         cts = rec[:, 0, 0]
         assert int(cts.sum()) == int(totals[2].item()), (cts, totals)
@@ -360,7 +369,7 @@ def main():
     if rank == 0:
         print(json.dumps(out), flush=True)
     sel.close()
-    if world > 1:
+    if dist_on:
         dist.destroy_process_group()
 
 
