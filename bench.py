@@ -10,7 +10,7 @@ Workload at 1 GPU: BASELINE.json configs[2] = 10 000 synthetic genomes, smh_a m=
 configuration the north_star target (>= 1e10 m=512 bucket-pair-comparisons/s, >= 40 % of the HBM
 roofline) is quoted on.  At N GPUs the genome count is scaled by sqrt(N) (per-GPU pair count fixed:
 weak scaling) and the pair space is sharded by query rows, equal pairs per rank; every rank holds a
-full replica of the sketches.
+full replica of the sketches; rows are dealt to ranks in interleaved blocks of 96.
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with the extra objects `roofline`
 (dominant kernel = stage 1, HIP-event timed inside the timed region) and `cpu_baseline` (the oracle,
@@ -105,6 +105,12 @@ def main():
     sel = pkg.Selector(local_rank)
     sel.attach(hll_t, aux_t, cards_t)
     sel.set_pipeline(args.pipeline)
+    IL_BLOCK = 96
+    if world > 1:
+        # shard the pair space by interleaved blocks of query rows: rank r owns the blocks b with b % world == r, i.e. an
+        # equal share of the pairs AND of the survivors (stage 2) -- a contiguous equal-pair cut would leave the last rank
+        # with a third of all rows, hence of all stage-2 work
+        sel.set_row_interleave(IL_BLOCK, world, rank)
     sel.set_stage2_grouping(not args.no_grouping)
     two_stage = cfg.p_aux > 0                      # BASELINE configs[4]: hll_a prefilter + smh_a
     if two_stage:
@@ -131,7 +137,7 @@ def main():
     z0 = int(np.argmax(cards >= 1.0)) if (cards >= 1.0).any() else n_genomes
     rc = pkg.host_lib().selhost_shard_rows(n_genomes, hi.ctypes.data if hi is not None else None, z0, world, bounds.ctypes.data)
     assert rc == 0
-    row_lo, row_hi = int(bounds[rank]), int(bounds[rank + 1])
+    row_lo, row_hi = (0, n_genomes) if world > 1 else (int(bounds[rank]), int(bounds[rank + 1]))
 
     # gather: ONE all_gather per step of a fixed-capacity record buffer whose record 0 carries the count.
     # The capacity is sized from the first (untimed) step: 1.25 x the largest per-rank count, so the timed loop
@@ -201,9 +207,9 @@ def main():
         allp = np.concatenate([rec[r, 1:1 + int(cts[r])].reshape(-1).view(PAIR_DTYPE) for r in range(world)])
         key = allp["i"].astype(np.int64) * n_genomes + allp["k"]
         assert len(np.unique(key)) == len(key), "duplicate pairs across shards"
-        for r in range(world):                        # every record sits in the row range of the rank that sent it
+        for r in range(world):                        # every record sits in a row block owned by the rank that sent it
             ii = rec[r, 1:1 + int(cts[r])].reshape(-1).view(PAIR_DTYPE)["i"]
-            assert ((ii >= bounds[r]) & (ii < bounds[r + 1])).all()
+            assert (world == 1) or (((ii // IL_BLOCK) % world) == r).all()
 
     out = None
     if rank == 0:

@@ -30,6 +30,37 @@ struct PassCounters {
 
 
 // ---------------------------------------------------------------------------------------------
+// RowMap: which query rows a pass owns.  Rows [row_begin, row_end) are cut into blocks of block_rows rows; the pass owns
+// the blocks b with b % n_parts == part.  n_parts = 1 (one block spanning the range) is the plain contiguous range; the
+// multi-GPU drivers use n_parts = world size with small blocks, so that every rank gets the same share of pairs AND of
+// survivors (a contiguous equal-pair cut gives the last rank ~35 % of all rows, hence of all stage-2 work, at 8 ranks).
+// Kernels address their query rows through "local tiles": tile t of height tile_h inside the owned blocks.
+// ---------------------------------------------------------------------------------------------
+struct RowMap {
+    int row_begin, row_end, block_rows, n_parts, part;
+    __host__ __device__ int total_blocks() const { return (int)(((long long)row_end - row_begin + block_rows - 1) / block_rows); }
+    __host__ __device__ int local_blocks() const { const int tb = total_blocks(); return part < tb ? (tb - part + n_parts - 1) / n_parts : 0; }
+    __host__ __device__ int tiles_per_block(int tile_h) const { return (block_rows + tile_h - 1) / tile_h; }
+    __host__ __device__ long long n_tiles(int tile_h) const { return (long long)local_blocks() * tiles_per_block(tile_h); }
+    __host__ __device__ bool owns(int i) const {
+        return i >= row_begin && i < row_end && ((i - row_begin) / block_rows) % n_parts == part;
+    }
+    // rows [*lo, *end) of local tile t; empty (lo == end) past the range
+    __device__ __forceinline__ void tile_rows(int t, int tile_h, int* lo, int* end) const {
+        const int tpb = tiles_per_block(tile_h);
+        const int lb = t / tpb, w = t % tpb;
+        const long long bs = (long long)row_begin + ((long long)lb * n_parts + part) * block_rows;
+        long long l = bs + (long long)w * tile_h;
+        long long e = l + tile_h;
+        if (e > bs + block_rows) e = bs + block_rows;
+        if (e > row_end) e = row_end;
+        if (l > row_end) l = row_end;
+        if (e < l) e = l;
+        *lo = (int)l; *end = (int)e;
+    }
+};
+
+// ---------------------------------------------------------------------------------------------
 // WaveAppender: per-wave staging of output records in LDS, flushed with ONE global atomic per >= 64 records.
 // A returning atomic on a single address sustains only ~90 operations/us chip-wide (MI355X_MICROARCH.md,
 // row "dequeue"), so appending survivors one atomicAdd at a time caps a pass at ~90 survivors/us

@@ -18,7 +18,7 @@ __device__ __forceinline__ bool cb_pred(double tau, u64 e1, u64 e2) {
 }
 
 __global__ void cb_bounds_kernel(const double* __restrict__ cards, int n, double tau, int use_cb,
-                                 int row_begin, int row_end, u64* __restrict__ ecard, int* __restrict__ hi,
+                                 RowMap rm, u64* __restrict__ ecard, int* __restrict__ hi,
                                  PassCounters* __restrict__ pc) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -45,7 +45,7 @@ __global__ void cb_bounds_kernel(const double* __restrict__ cards, int n, double
         h = lo;
     }
     hi[i] = h;
-    if (i >= row_begin && i < row_end) {
+    if (rm.owns(i)) {
         // pairs of this row inside the pair space: k in [max(i+1, z0'), h]; z0 may not be published yet,
         // so count candidates with e_k != 0 directly from the sorted property: e_k == 0 only for k < z0.
         // first k > i with e_k != 0: if e1 != 0 it is i+1, else binary search.

@@ -251,12 +251,13 @@ void ertl_select_kernel(const uint32_t* __restrict__ counts, const u64* __restri
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kBlock)
 void enum_pairs_kernel(int n, const int* __restrict__ hi, const PassCounters* __restrict__ pc_in,
-                       int row_begin, int row_end, int n_rows_grid,
+                       RowMap rm, int n_rows_grid,
                        selhip_int2_t* __restrict__ out, u64 out_cap, PassCounters* __restrict__ pc) {
     __shared__ selhip_int2_t app_lds[kWavesPerBlock * kAppendCap];
-    const int i = row_begin + (int)(blockIdx.x % n_rows_grid);
+    int i, i_e;
+    rm.tile_rows((int)(blockIdx.x % n_rows_grid), 1, &i, &i_e);
     const int chunk = blockIdx.x / n_rows_grid;
-    if (i >= row_end) return;
+    if (i >= i_e) return;
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
     const int kmin = max(i + 1, pc_in->z0p1 ? pc_in->z0p1 - 1 : n);

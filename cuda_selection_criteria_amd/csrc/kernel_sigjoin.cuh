@@ -98,7 +98,7 @@ template <int NB>
 __global__ __launch_bounds__(kBlock)
 void sig_join_kernel(const uint32_t* __restrict__ sigT, int n, int n_pad,
                      const int* __restrict__ hi, const PassCounters* __restrict__ pc_in,
-                     int row_begin, int row_end, int n_tiles, int group_base, int qt,
+                     RowMap rm, int n_tiles, int group_base, int qt,
                      selhip_int2_t* __restrict__ cand, u64 cand_cap, PassCounters* __restrict__ pc) {
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
@@ -108,8 +108,9 @@ void sig_join_kernel(const uint32_t* __restrict__ sigT, int n, int n_pad,
     if (k_base >= n) return;
     const int z0 = pc_in->z0p1 ? pc_in->z0p1 - 1 : n;
     const int k_last = k_base + kWave - 1;
-    const int i_lo = row_begin + tile * qt;                                   // qt is a multiple of 16
-    const int i_hi = min(min(i_lo + qt, row_end), k_last);                    // need i < k for some lane
+    int i_lo, i_end;
+    rm.tile_rows(tile, qt, &i_lo, &i_end);                                    // qt is a multiple of 16
+    const int i_hi = min(i_end, k_last);                                      // need i < k for some lane
     if (i_lo >= i_hi || k_last < z0) return;
     if (hi[i_hi - 1] < k_base) return;                                        // hi is non-decreasing
 
@@ -171,7 +172,7 @@ void sigkey_build_kernel(const uint32_t* __restrict__ sigT, int n, int n_pad, in
 __global__ __launch_bounds__(kBlock)
 void run_emit_kernel(const u64* __restrict__ keys, const int* __restrict__ vals, long long total,
                      const uint32_t* __restrict__ sigQ, int nb, const u64* __restrict__ aux, int m, int n_rows, int n_bands,
-                     int n, const int* __restrict__ hi, const PassCounters* __restrict__ pc_in, int row_begin, int row_end,
+                     int n, const int* __restrict__ hi, const PassCounters* __restrict__ pc_in, RowMap rm,
                      selhip_int2_t* __restrict__ surv, u64 surv_cap, PassCounters* __restrict__ pc) {
     __shared__ selhip_int2_t app_lds[kWavesPerBlock * kAppendCap];
     const int lane = threadIdx.x & (kWave - 1);
@@ -194,7 +195,7 @@ void run_emit_kernel(const u64* __restrict__ keys, const int* __restrict__ vals,
             if (act) {
                 const int g2 = vals[p + step];
                 i = min(g, g2); k = max(g, g2);
-                cand = i != k && i >= row_begin && i < row_end && k >= max(i + 1, z0) && k <= min(hi[i], n - 1);
+                cand = i != k && rm.owns(i) && k >= max(i + 1, z0) && k <= min(hi[i], n - 1);
                 if (cand) {                                        // take the pair from its first matching band only
                     const uint32_t* qi = sigQ + (long long)i * nb;
                     const uint32_t* qk = sigQ + (long long)k * nb;

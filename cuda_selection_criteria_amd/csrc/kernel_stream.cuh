@@ -44,7 +44,7 @@ template <int NCH, int LOG2R>
 __global__ __launch_bounds__(kBlock, (NCH <= 4 ? 3 : 2))      // 3 waves/SIMD = at most 168 VGPRs (measured: 2 waves cost 17 %)
 void smh_stream_kernel(const u64x2* __restrict__ aux, int n, int r_rt,
                        const int* __restrict__ hi, const PassCounters* __restrict__ pc_in,
-                       int row_begin, int row_end, int n_tiles, int chunk_base,
+                       RowMap rm, int n_tiles, int chunk_base,
                        selhip_int2_t* __restrict__ surv, u64 surv_cap, PassCounters* __restrict__ pc) {
     constexpr int Q = kQueryVgprBudget / NCH;
     constexpr int ROWV = NCH * kWave;                 // u64x2 per sketch row
@@ -53,8 +53,10 @@ void smh_stream_kernel(const u64x2* __restrict__ aux, int n, int r_rt,
 
     const int tile = blockIdx.x % n_tiles;
     const int chunk = blockIdx.x / n_tiles;
-    const int i0 = row_begin + tile * Q;
-    const int i_last = min(i0 + Q, row_end) - 1;
+    int i0, i_end;
+    rm.tile_rows(tile, Q, &i0, &i_end);
+    if (i0 >= i_end) return;
+    const int i_last = i_end - 1;
     const int z0 = pc_in->z0p1 ? pc_in->z0p1 - 1 : n;
     const int k0 = chunk_base + chunk * kChunk;
     const int kmax = hi[i_last];                      // hi is non-decreasing in i
@@ -132,7 +134,7 @@ void smh_stream_kernel(const u64x2* __restrict__ aux, int n, int r_rt,
             }
             if (pass) {
                 const int i = i0 + a;
-                if (i < row_end && k > i && k >= z0 && k <= hi[i]) app.push_uniform(i, k, lane);
+                if (i < i_end && k > i && k >= z0 && k <= hi[i]) app.push_uniform(i, k, lane);
             }
         }
     }
@@ -158,12 +160,13 @@ __device__ __forceinline__ bool smh_a_lane(const u64* __restrict__ v1, const u64
 __global__ __launch_bounds__(kBlock)
 void smh_generic_kernel(const u64* __restrict__ aux, int n, int m, int n_rows, int n_bands,
                         const int* __restrict__ hi, const PassCounters* __restrict__ pc_in,
-                        int row_begin, int row_end, int n_rows_grid,
+                        RowMap rm, int n_rows_grid,
                         selhip_int2_t* __restrict__ surv, u64 surv_cap, PassCounters* __restrict__ pc) {
     __shared__ selhip_int2_t app_lds[kWavesPerBlock * kAppendCap];
-    const int i = row_begin + (int)(blockIdx.x % n_rows_grid);
+    int i, i_e;
+    rm.tile_rows((int)(blockIdx.x % n_rows_grid), 1, &i, &i_e);
     const int chunk = blockIdx.x / n_rows_grid;
-    if (i >= row_end) return;
+    if (i >= i_e) return;
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
     const int z0 = pc_in->z0p1 ? pc_in->z0p1 - 1 : n;

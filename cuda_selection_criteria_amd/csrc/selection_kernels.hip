@@ -142,6 +142,7 @@ struct selhip_ctx {
     hipEvent_t ev_start = nullptr, ev_end = nullptr, ev_chunk[8] = {};
     int n_chunks_last = 1;
     int pipeline = -1;                  // -1 auto, 0 off, >0 forced chunk count
+    int il_block = 96, il_parts = 1, il_part = 0;    // row interleave (selhip_ctx_set_row_interleave); il_parts 1 = contiguous
     int join_qt = 96;                   // query rows per signature-join block (multiple of 16); measured flat 48..192
     bool group_stage2 = true;           // bucket survivors by query row before stage 2a (hll_union_hist_runs_kernel)
 
@@ -218,12 +219,24 @@ double relerr_scaled_for(int p) {
 bool is_pow2(int x) { return x > 0 && (x & (x - 1)) == 0; }
 int ilog2(int x) { int l = 0; while ((1 << l) < x) ++l; return l; }
 
+// RowMap of the query rows [rb, re) under the context's interleave setting (selhip_ctx_set_row_interleave)
+RowMap row_map(const selhip_ctx* c, int rb, int re) {
+    RowMap rm;
+    rm.row_begin = rb; rm.row_end = re;
+    if (c->il_parts > 1) { rm.block_rows = c->il_block; rm.n_parts = c->il_parts; rm.part = c->il_part; }
+    else                 { rm.block_rows = std::max(1, re - rb); rm.n_parts = 1; rm.part = 0; }
+    return rm;
+}
+
 // ---- stage-1 dispatch ------------------------------------------------------------------------
 template <int NCH, int LOG2R>
 hipError_t launch_stream(selhip_ctx* c, const StageIO& io, int r_rt, int row_begin, int row_end) {
     constexpr int Q = kQueryVgprBudget / NCH;
     const int n = (int)c->n;
-    const int n_tiles = (row_end - row_begin + Q - 1) / Q;
+    const RowMap rm = row_map(c, row_begin, row_end);
+    const long long n_tiles_ll = rm.n_tiles(Q);
+    if (n_tiles_ll > 0x7FFFFFFFll) return hipErrorInvalidValue;
+    const int n_tiles = (int)n_tiles_ll;
     // candidate columns that can matter: k in (row_begin, n)
     const int chunk_base = ((row_begin + 1) / kChunk) * kChunk;
     const int n_chunks = (n - chunk_base + kChunk - 1) / kChunk;
@@ -232,7 +245,7 @@ hipError_t launch_stream(selhip_ctx* c, const StageIO& io, int r_rt, int row_beg
     if (blocks > 0x7FFFFFFFll) return hipErrorInvalidValue;
     hipLaunchKernelGGL((smh_stream_kernel<NCH, LOG2R>), dim3((unsigned)blocks), dim3(kBlock), 0, io.st,
                        reinterpret_cast<const u64x2*>(c->d_aux), n, r_rt, c->hi.p, c->pc.p,
-                       row_begin, row_end, n_tiles, chunk_base, io.surv, io.cap, io.pc);
+                       rm, n_tiles, chunk_base, io.surv, io.cap, io.pc);
     return hipGetLastError();
 }
 
@@ -265,14 +278,15 @@ hipError_t launch_stage1(selhip_ctx* c, const StageIO& io, int n_rows, int n_ban
             case 16: return launch_stream_r<16>(c, io, n_rows, rb, re);
         }
     }
-    const int rows = re - rb;
+    const RowMap rm = row_map(c, rb, re);
+    const long long rows = rm.n_tiles(1);
     const int n = (int)c->n;
     const int chunks = (n + kBlock - 1) / kBlock;
-    const long long blocks = (long long)rows * chunks;
+    const long long blocks = rows * chunks;
     if (blocks <= 0) return hipSuccess;
     if (blocks > 0x7FFFFFFFll) return hipErrorInvalidValue;
     hipLaunchKernelGGL(smh_generic_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, io.st,
-                       c->d_aux, n, c->m, n_rows, n_bands, c->hi.p, c->pc.p, rb, re, rows,
+                       c->d_aux, n, c->m, n_rows, n_bands, c->hi.p, c->pc.p, rm, (int)rows,
                        io.surv, io.cap, io.pc);
     return hipGetLastError();
 }
@@ -289,7 +303,10 @@ template <int NB>
 hipError_t launch_join(selhip_ctx* c, const StageIO& io, int n_pad, int rb, int re) {
     const int n = (int)c->n;
     const int qt = c->join_qt;          // query rows per block (multiple of 16)
-    const int n_tiles = (re - rb + qt - 1) / qt;
+    const RowMap rm = row_map(c, rb, re);
+    const long long n_tiles_ll = rm.n_tiles(qt);
+    if (n_tiles_ll > 0x7FFFFFFFll) return hipErrorInvalidValue;
+    const int n_tiles = (int)n_tiles_ll;
     const int group_base = ((rb + 1) / kWave / kWavesPerBlock) * kWavesPerBlock;      // candidates k > row_begin
     const int n_groups = (n + kWave - 1) / kWave - group_base;
     const int n_gblocks = (n_groups + kWavesPerBlock - 1) / kWavesPerBlock;
@@ -297,7 +314,7 @@ hipError_t launch_join(selhip_ctx* c, const StageIO& io, int n_pad, int rb, int 
     const long long blocks = (long long)n_tiles * n_gblocks;
     if (blocks > 0x7FFFFFFFll) return hipErrorInvalidValue;
     hipLaunchKernelGGL((sig_join_kernel<NB>), dim3((unsigned)blocks), dim3(kBlock), 0, io.st,
-                       c->sigT.p, n, n_pad, c->hi.p, c->pc.p, rb, re, n_tiles, group_base, qt,
+                       c->sigT.p, n, n_pad, c->hi.p, c->pc.p, rm, n_tiles, group_base, qt,
                        io.cand, io.cap, io.pc);
     return hipGetLastError();
 }
@@ -353,7 +370,7 @@ hipError_t launch_stage1_hashjoin(selhip_ctx* c, const StageIO& io, int n_rows, 
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(run_emit_kernel, dim3(grid_for((u64)total, kBlock, 8192)), dim3(kBlock), 0, io.st,
                        c->hj_keys_out.p, c->hj_vals_out.p, total, c->sigQ.p, n_bands, c->d_aux, c->m, n_rows, n_bands,
-                       n, c->hi.p, c->pc.p, rb, re, io.surv, io.cap, io.pc);
+                       n, c->hi.p, c->pc.p, row_map(c, rb, re), io.surv, io.cap, io.pc);
     return hipGetLastError();
 }
 
@@ -452,7 +469,7 @@ int pipeline_chunks(const selhip_ctx* c) {
     // cfg3 0.61 -> 0.74 / 0.85 ms with 2 / 4 chunks, cfg4 5.05 -> 5.11 / 5.14 ms: the join (VALU issue) and the
     // histogram kernel (VALU + LDS atomics + memory) contend for the same issue slots, and every chunk adds launches.
     // So the automatic setting is OFF; the mechanism stays for workloads with a heavier memory-bound stage 2.
-    if (c->pipeline <= 1) return 1;
+    if (c->pipeline <= 1 || c->il_parts > 1) return 1;
     return std::min(c->pipeline, kMaxChunks);
 }
 
@@ -479,7 +496,7 @@ int enqueue_pass(selhip_ctx* c) {
     {
         TimerScope t(c, T_PREP);
         hipLaunchKernelGGL(cb_bounds_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream,
-                           c->d_cards, n, tau, c->mode == SELHIP_MODE_CB_SMH ? 1 : 0, rb, re, c->ecard.p, c->hi.p, pc0);
+                           c->d_cards, n, tau, c->mode == SELHIP_MODE_CB_SMH ? 1 : 0, row_map(c, rb, re), c->ecard.p, c->hi.p, pc0);
         HIPCHK(&c->err, hipGetLastError());
     }
     const bool smh_crit = crit == SELHIP_CRIT_SMH_A || crit == SELHIP_CRIT_HLL_A_SMH_A;
@@ -548,12 +565,13 @@ int enqueue_pass(selhip_ctx* c) {
         else              HIPCHK(&c->err, launch_stage1(c, io, c->n_rows, c->n_bands, rb, re));
     } else {
         TimerScope t(c, T_STAGE1);
-        const int rows = re - rb;
-        const long long blocks = (long long)rows * ((n + kBlock - 1) / kBlock);
+        const RowMap rm = row_map(c, rb, re);
+        const long long rows = rm.n_tiles(1);
+        const long long blocks = rows * ((n + kBlock - 1) / kBlock);
         if (blocks > 0x7FFFFFFFll) { set_err(&c->err, "row range too large"); return SELHIP_E_BADARG; }
         if (blocks > 0) {
             hipLaunchKernelGGL(enum_pairs_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, c->stream, n, c->hi.p, pc0,
-                               rb, re, rows, c->cand.p, (u64)c->cand.cap, io.pc);
+                               rm, (int)rows, c->cand.p, (u64)c->cand.cap, io.pc);
             HIPCHK(&c->err, hipGetLastError());
         }
     }
@@ -741,6 +759,19 @@ int selhip_ctx_set_stream(selhip_ctx* c, void* hip_stream) {
 int selhip_ctx_set_fp_mode(selhip_ctx* c, int fp_mode) {
     if (!c || (fp_mode != SELHIP_FP_FMA && fp_mode != SELHIP_FP_STRICT)) return SELHIP_E_BADARG;
     c->fp_mode = fp_mode;
+    return SELHIP_OK;
+}
+
+int selhip_ctx_set_row_interleave(selhip_ctx* c, int block_rows, int n_parts, int part) {
+    if (!c) return SELHIP_E_BADARG;
+    if (n_parts <= 1) { c->il_parts = 1; c->il_part = 0; return SELHIP_OK; }
+    if (block_rows < 32 || block_rows % 32 || part < 0 || part >= n_parts) {
+        set_err(&c->err, "row interleave: block_rows must be a multiple of 32 (>= 32) and 0 <= part < n_parts");
+        return SELHIP_E_BADARG;
+    }
+    c->il_block = block_rows; c->il_parts = n_parts; c->il_part = part;
+    c->join_qt = std::min(c->join_qt, block_rows);
+    while (block_rows % c->join_qt) c->join_qt -= 16;          // tile height must divide the block (both multiples of 16)
     return SELHIP_OK;
 }
 
@@ -1216,14 +1247,6 @@ struct Rccl {
 Rccl g_rccl;
 constexpr int kNcclChar = 0;     // ncclDataType_t ncclChar (rccl.h)
 
-// equal-pair row boundaries over [0, n) for `parts` devices (triangular pair space)
-void shard_rows_host(long long n, int parts, std::vector<long long>& bnd) {
-    bnd.assign((size_t)parts + 1, 0);
-    std::vector<long long> tmp((size_t)parts + 1);
-    chunk_rows(n, 0, n, parts, tmp.data());
-    for (int k = 0; k <= parts; ++k) bnd[(size_t)k] = tmp[(size_t)k];
-}
-
 }  // namespace
 
 extern "C" {
@@ -1236,8 +1259,6 @@ int selhip_multi_select(const int* devices, int n_devices,
     if (gather < SELHIP_GATHER_HOST || gather > SELHIP_GATHER_RCCL_OR_HOST) { set_err(nullptr, "bad gather mode"); return SELHIP_E_BADARG; }
     *count_out = 0;
     const int G = n_devices;
-    std::vector<long long> bnd;
-    shard_rows_host(n, G, bnd);
 
     // RCCL communicators (single process, one per device)
     std::vector<void*> comms((size_t)G, nullptr);
@@ -1267,7 +1288,9 @@ int selhip_multi_select(const int* devices, int n_devices,
             selhip_ctx* c = ctxs[(size_t)g];
             r = selhip_ctx_set_fp_mode(c, fp_mode);
             if (!r) r = selhip_ctx_upload(c, h_hll, h_aux, h_cards, n, m, p_hll);
-            if (!r) r = selhip_ctx_run(c, mode, algo, tau_f, n_rows, n_bands, bnd[(size_t)g], bnd[(size_t)g + 1]);
+            // interleaved row blocks: every device gets the same share of pairs and of survivors
+            if (!r) r = selhip_ctx_set_row_interleave(c, 96, G, g);
+            if (!r) r = selhip_ctx_run(c, mode, algo, tau_f, n_rows, n_bands, 0, n);
             if (!r) { counts[(size_t)g] = selhip_ctx_result_count(c); r = selhip_ctx_stats(c, st[(size_t)g].data()); }
             if (r) { rc[(size_t)g] = r; errs[(size_t)g] = selhip_last_error(c); }
         });

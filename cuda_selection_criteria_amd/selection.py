@@ -157,6 +157,10 @@ class Selector:
         """-1 auto, 0 off, 2..8 forced: overlap of stage 1 (next row chunk) with stage 2 (previous chunk)"""
         check(self._lib.selhip_ctx_set_pipeline(self._ctx, chunks), self._ctx)
 
+    def set_row_interleave(self, block_rows: int, n_parts: int, part: int):
+        """the following runs evaluate only the row blocks b (of block_rows rows) with b % n_parts == part"""
+        check(self._lib.selhip_ctx_set_row_interleave(self._ctx, block_rows, n_parts, part), self._ctx)
+
     def set_param(self, name: str, value: int):
         check(self._lib.selhip_ctx_set_param(self._ctx, name.encode(), value), self._ctx)
 

@@ -115,6 +115,11 @@ int selhip_ctx_set_stream(selhip_ctx* ctx, void* hip_stream);
  * of chunk c+1 runs on one internal stream while stage 2 (HLL union histograms, memory/LDS-bound) of chunk c runs on
  * another.  -1 / 0 / 1 = off (the default: measured slower or equal on MI355X), 2..8 = chunk count. */
 int selhip_ctx_set_pipeline(selhip_ctx* ctx, int chunks);
+/* Row interleave for sharding a pass over several devices/ranks: the rows [row_begin, row_end) of the following runs are
+ * cut into blocks of block_rows rows (a multiple of 32) and the run evaluates only the blocks b with b % n_parts == part.
+ * Every rank then gets the same share of the pair space AND of the survivors, whatever the triangle's shape (a contiguous
+ * equal-pair cut hands the last of 8 ranks ~35 % of all rows, i.e. of all stage-2 work).  n_parts <= 1 switches it off. */
+int selhip_ctx_set_row_interleave(selhip_ctx* ctx, int block_rows, int n_parts, int part);
 /* Tunables (integers by name): "join_qt" = query rows per block of the signature join (multiple of 16, default 96). */
 int selhip_ctx_set_param(selhip_ctx* ctx, const char* name, int value);
 /* Stage 2 grouping (default on): the pairs that reach the HLL-14 stage are bucketed by query row (counting sort) so

@@ -185,6 +185,49 @@ def test_pipelined_pass_equals_plain(oracle):
                         assert s["survivors"] == st["survivors"] and s["evaluated"] == st["evaluated"]
 
 
+def test_interleaved_row_blocks_tile_the_pair_space(oracle):
+    """selhip_ctx_set_row_interleave: the parts' results are disjoint, their union is the whole, their evaluated-pair
+    counts add up -- every stage-1 algorithm, CB and non-CB, and the explicit pair enumeration of hll_a"""
+    cfg = make_golden.GOLDEN_SYNTH["synth_flat_n1000_m256"]
+    hll, aux, cards, _, aux_hll = sorted_set(cfg, oracle)
+    r, b = pkg.banding(cfg.m, cfg.tau)
+    with Selector(0) as sel:
+        sel.upload(hll, aux, cards)
+        sel.upload_aux_hll(aux_hll, 8)
+        for crit, algos in ((pkg.CRIT_SMH_A, (ALGO_SIG, ALGO_STREAM, ALGO_HASHJOIN)), (pkg.CRIT_HLL_A, (ALGO_AUTO,)),
+                            (pkg.CRIT_HLL_A_SMH_A, (ALGO_AUTO,))):
+            sel.set_criterion(crit)
+            for mode, use_cb in ((MODE_CB_SMH, True), (MODE_SMH, False)):
+                want, st = oracle.select(hll, aux, cards, cfg.tau, r, b, use_cb=use_cb, criterion=crit, aux_hll=aux_hll, p_aux=8)
+                for algo in algos:
+                    for parts, block in ((2, 96), (3, 32), (8, 64), (5, 128)):
+                        got, ev = [], 0
+                        for part in range(parts):
+                            sel.set_row_interleave(block, parts, part)
+                            res = sel.run(cfg.tau, mode, r, b, algo=algo)
+                            assert (((res["i"] // block) % parts) == part).all()
+                            got.append(res)
+                            ev += sel.stats()["evaluated"]
+                        sel.set_row_interleave(0, 1, 0)
+                        cat = np.concatenate(got)
+                        cat = cat[np.lexsort((cat["k"], cat["i"]))]
+                        assert_same_pairs(cat, want)
+                        assert ev == st["evaluated"], (crit, mode, algo, parts, ev, st)
+        # a sub-range of rows combined with the interleave
+        sel.set_criterion(pkg.CRIT_SMH_A)
+        want, _ = oracle.select(hll, aux, cards, cfg.tau, r, b)
+        got = []
+        for part in range(4):
+            sel.set_row_interleave(32, 4, part)
+            got.append(sel.run(cfg.tau, MODE_CB_SMH, r, b, rows=(101, 877)))
+        sel.set_row_interleave(0, 1, 0)
+        cat = np.concatenate(got)
+        cat = cat[np.lexsort((cat["k"], cat["i"]))]
+        assert_same_pairs(cat, want[(want["i"] >= 101) & (want["i"] < 877)])
+        with pytest.raises(pkg.SelhipError):
+            sel.set_row_interleave(33, 2, 0)
+
+
 def test_stage2_grouping_on_off(oracle):
     """survivors bucketed by query row (run-aware histogram kernel) vs the ungrouped kernel: identical results"""
     cfg = make_golden.GOLDEN_SYNTH["synth_spread_n600_m64"]
