@@ -104,11 +104,13 @@ void hll_union_hist_kernel(const uint8_t* __restrict__ hll, int p,
 }
 
 // ---------------------------------------------------------------------------------------------
-// Grouping survivors by query row, and the histogram kernel that exploits it.  Stage 2a is bound by the bytes it
-// pulls through the memory system (32 KiB per pair; PMC: LDS array 30 % busy, VALU 48 %), and a query row with g
-// survivors is read g times.  csr_count / csr_fill bucket the pair list by its first rank (counting sort, order inside
-// a bucket free), and hll_union_hist_runs_kernel lets each wave walk kRunLen consecutive pairs of the grouped list with
-// row x held in registers for as long as x does not change: (g + 1) instead of 2g row reads per group.
+// Grouping survivors by query row, and the histogram kernel that exploits it.  Stage 2a issues one conflict-free
+// `ds_add_u32` per 64 register pairs and the LDS retires one such wave-instruction every ~5 cycles per CU
+// (scripts/microbench/lds_atomic_rate.hip): 256 of them per pair = the kernel's floor (cfg3: 45 000 pairs -> ~95 us).  To sit
+// on that floor the 32 KiB of rows per pair must come from L2 as often as possible, so csr_count / csr_fill bucket the pair
+// list by its first rank (counting sort, order inside a bucket free) and the histogram kernel hands neighbouring pairs of
+// the grouped list to waves that run at the same time on the same XCD: the query row of a group is then an L2 hit for
+// all but one of them (ungrouped list: 188 us instead of 118 us at cfg3).
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kBlock)
 void csr_count_kernel(const selhip_int2_t* __restrict__ pairs, const u64* __restrict__ n_dev, u64 cap, int* __restrict__ cnt) {
@@ -128,41 +130,85 @@ void csr_fill_kernel(const selhip_int2_t* __restrict__ pairs, const u64* __restr
     }
 }
 
-constexpr int kRunLen = 8;
+// hll_union_hist_runs_kernel (p = 14): one wave per block with a lane-private [bin][lane] histogram (16 KiB of LDS).
+//  * block b works in the (b % 8)-th eighth of the list (round-robin block dispatch puts it on XCD b % 8) and the waves
+//    of an XCD stride through that eighth together, `run_len` (default 1) consecutive pairs at a time;
+//  * the LDS address of a register pair is formed by ONE VALU instruction: with the histogram at LDS offset 0, [bin][lane]
+//    puts lane*4 in byte 0 and the bin in byte 1 of the address, and `v_max_u32_sdwa dst_sel:BYTE_1
+//    dst_unused:UNUSED_PRESERVE` writes max(byte_s(x), byte_s(y)) straight into byte 1 of a register that keeps lane*4
+//    (the compiler's own sequence -- max, shift, mask, add -- is kept as the path for a histogram not at offset 0);
+//  * the histogram is zeroed once per wave: bins only grow, and a pair's counts are the difference of the running column
+//    sums before and after it (unsigned arithmetic: wrap-around cancels), which removes 64 LDS stores per pair.
+constexpr int kHistSpanBlocks = 16384;      // one-wave blocks (a multiple of 8); ~8 resident per CU, the rest balance the tail
+typedef __attribute__((address_space(3))) uint32_t lds_u32_t;
 
-__global__ __launch_bounds__(kBlock)
+#define SELHIP_SDWA_MAX_B1(addr, a, b, SEL)                                                                    \
+    asm("v_max_u32_sdwa %0, %1, %2 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:" SEL " src1_sel:" SEL   \
+        : "+v"(addr) : "v"(a), "v"(b))
+
+__device__ __forceinline__ void hist_add_max_word(uint32_t& a0, uint32_t& a1, uint32_t& a2, uint32_t& a3, uint32_t x, uint32_t y) {
+    SELHIP_SDWA_MAX_B1(a0, x, y, "BYTE_0");
+    __hip_atomic_fetch_add((lds_u32_t*)(uintptr_t)a0, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    SELHIP_SDWA_MAX_B1(a1, x, y, "BYTE_1");
+    __hip_atomic_fetch_add((lds_u32_t*)(uintptr_t)a1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    SELHIP_SDWA_MAX_B1(a2, x, y, "BYTE_2");
+    __hip_atomic_fetch_add((lds_u32_t*)(uintptr_t)a2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    SELHIP_SDWA_MAX_B1(a3, x, y, "BYTE_3");
+    __hip_atomic_fetch_add((lds_u32_t*)(uintptr_t)a3, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+__global__ __launch_bounds__(kWave)
 void hll_union_hist_runs_kernel(const uint8_t* __restrict__ hll, const selhip_int2_t* __restrict__ pairs,
                                 const u64* __restrict__ n_pairs_dev, u64 cap, uint32_t* __restrict__ counts,
-                                u64 chunk_off, u64 chunk_len) {
-    __shared__ uint32_t hist[kWavesPerBlock][64 * kWave];     // 64 KiB, one lane-private histogram per wave
-    const int lane = threadIdx.x & (kWave - 1);
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
+                                u64 chunk_off, u64 chunk_len, int run_len) {
+    __shared__ __attribute__((aligned(16))) uint32_t hist[64 * kWave];     // [bin][lane], 16 KiB: the only LDS object -> offset 0
+    const int lane = threadIdx.x;
     u64 n_pairs = *n_pairs_dev;
     if (n_pairs > cap) n_pairs = cap;
     n_pairs = n_pairs > chunk_off ? min(n_pairs - chunk_off, chunk_len) : 0;
     pairs += chunk_off;
-    uint32_t* my = hist[wave];
-    uint32_t* col = my + lane;
-    const u64 n_tasks = (n_pairs + kRunLen - 1) / kRunLen;
-    for (u64 task = (u64)blockIdx.x * kWavesPerBlock + wave; task < n_tasks; task += (u64)gridDim.x * kWavesPerBlock) {
-        const u64 j0 = task * kRunLen, j1 = min(j0 + kRunLen, n_pairs);
-        int cur_x = -1;
-        uint4 xa[16];
-        for (u64 j = j0; j < j1; ++j) {
-            const selhip_int2_t pr = pairs[j];
-            const uint4* b4 = reinterpret_cast<const uint4*>(hll + (long long)pr.y * 16384);
-            uint4 xb[16];
+    const u64 per_xcd = gridDim.x >> 3;                                   // host launches a multiple of 8 blocks
+    const u64 n_tasks = (n_pairs + run_len - 1) / run_len;
+    const u64 tasks_per_xcd = (n_tasks + 7) >> 3;
+    const u64 t_begin = (u64)(blockIdx.x & 7) * tasks_per_xcd, t_end = min(t_begin + tasks_per_xcd, n_tasks);
+    const bool lds_at_zero = (uint32_t)(uintptr_t)hist == 0u;
+    uint4* const row4 = reinterpret_cast<uint4*>(hist + lane * kWave);     // lane l owns bin l in the zero / reduce steps
+    uint32_t* const col = hist + lane;
+    uint32_t a0 = (uint32_t)lane * 4u, a1 = a0, a2 = a0, a3 = a0;
+    constexpr uint32_t kMask = 0x3F3F3F3Fu;                               // register values are <= 64-p+1 < 64
+    int cur_x = -1;
+    uint4 xa[16];
+    uint32_t prev = 0;
 #pragma unroll
-            for (int it = 0; it < 16; ++it) xb[it] = b4[it * kWave + lane];
-            if (pr.x != cur_x) {                                  // wave-uniform: the row of the group leader changes
-                const uint4* a4 = reinterpret_cast<const uint4*>(hll + (long long)pr.x * 16384);
+    for (int t = 0; t < 16; ++t) row4[(t + lane) & 15] = make_uint4(0u, 0u, 0u, 0u);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    for (u64 task = t_begin + (blockIdx.x >> 3); task < t_end; task += per_xcd) {
+    const u64 j0 = task * run_len, j1 = min(j0 + run_len, n_pairs);
+    selhip_int2_t pr = pairs[j0];
+    for (u64 j = j0; j < j1; ++j) {
+        const uint4* b4 = reinterpret_cast<const uint4*>(hll + (long long)pr.y * 16384);
+        uint4 xb[16];
 #pragma unroll
-                for (int it = 0; it < 16; ++it) xa[it] = a4[it * kWave + lane];
-                cur_x = pr.x;
+        for (int it = 0; it < 16; ++it) xb[it] = b4[it * kWave + lane];
+        if (pr.x != cur_x) {                                              // wave-uniform: the query row changes
+            const uint4* a4 = reinterpret_cast<const uint4*>(hll + (long long)pr.x * 16384);
+#pragma unroll
+            for (int it = 0; it < 16; ++it) {
+                uint4 v = a4[it * kWave + lane];
+                xa[it] = make_uint4(v.x & kMask, v.y & kMask, v.z & kMask, v.w & kMask);
             }
-#pragma unroll 8
-            for (int b = 0; b < 64; ++b) col[b * kWave] = 0;
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            cur_x = pr.x;
+        }
+        if (j + 1 < j1) pr = pairs[j + 1];                                // next pair's ranks arrive while this one is binned
+        if (lds_at_zero) {
+#pragma unroll
+            for (int it = 0; it < 16; ++it) {
+                hist_add_max_word(a0, a1, a2, a3, xa[it].x, xb[it].x & kMask);
+                hist_add_max_word(a0, a1, a2, a3, xa[it].y, xb[it].y & kMask);
+                hist_add_max_word(a0, a1, a2, a3, xa[it].z, xb[it].z & kMask);
+                hist_add_max_word(a0, a1, a2, a3, xa[it].w, xb[it].w & kMask);
+            }
+        } else {
 #pragma unroll
             for (int it = 0; it < 16; ++it) {
                 hist_add_word(col, max_u8x4(xa[it].x, xb[it].x));
@@ -170,14 +216,18 @@ void hll_union_hist_runs_kernel(const uint8_t* __restrict__ hll, const selhip_in
                 hist_add_word(col, max_u8x4(xa[it].z, xb[it].z));
                 hist_add_word(col, max_u8x4(xa[it].w, xb[it].w));
             }
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            uint32_t sacc = 0;
-            const uint32_t* rowp = my + lane * kWave;
-#pragma unroll 8
-            for (int t = 0; t < kWave; ++t) sacc += rowp[(t + lane) & (kWave - 1)];
-            counts[j * 64 + lane] = sacc;
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        uint32_t sacc = 0;
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            const uint4 v = row4[(t + lane) & 15];
+            sacc += (v.x + v.y) + (v.z + v.w);
+        }
+        counts[j * 64 + lane] = sacc - prev;                              // the histogram is never re-zeroed: difference of running sums
+        prev = sacc;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    }
     }
 }
 

@@ -79,14 +79,25 @@ template <int NB, int J>
 __device__ __forceinline__ void join_one_query(const uint32_t (&c)[NB], const uint32_t (&qv)[NB], int i, int i_hi,
                                                int k, int lane, int z0, int n, const int* __restrict__ hi,
                                                WaveAppender& app) {
-    // two independent chains of v_min3_u32(acc, x, y): 1.5 VALU per band
-    uint32_t acc0 = 0xFFFFFFFFu, acc1 = 0xFFFFFFFFu;
+    // independent chains of v_min3_u32(acc, x, y): 1.5 VALU per band; four chains (when there are enough bands) so that
+    // a wave has issue work while a chain waits on its own result
+    uint32_t acc0 = 0xFFFFFFFFu, acc1 = 0xFFFFFFFFu, acc2 = 0xFFFFFFFFu, acc3 = 0xFFFFFFFFu;
+    if constexpr (NB >= 16) {
 #pragma unroll
-    for (int b = 0; b < NB; b += 4) {
-        acc0 = min(min(acc0, c[b] ^ dpp_row_bcast<J>(qv[b])), c[b + 1] ^ dpp_row_bcast<J>(qv[b + 1]));
-        acc1 = min(min(acc1, c[b + 2] ^ dpp_row_bcast<J>(qv[b + 2])), c[b + 3] ^ dpp_row_bcast<J>(qv[b + 3]));
+        for (int b = 0; b < NB; b += 8) {
+            acc0 = min(min(acc0, c[b] ^ dpp_row_bcast<J>(qv[b])), c[b + 1] ^ dpp_row_bcast<J>(qv[b + 1]));
+            acc1 = min(min(acc1, c[b + 2] ^ dpp_row_bcast<J>(qv[b + 2])), c[b + 3] ^ dpp_row_bcast<J>(qv[b + 3]));
+            acc2 = min(min(acc2, c[b + 4] ^ dpp_row_bcast<J>(qv[b + 4])), c[b + 5] ^ dpp_row_bcast<J>(qv[b + 5]));
+            acc3 = min(min(acc3, c[b + 6] ^ dpp_row_bcast<J>(qv[b + 6])), c[b + 7] ^ dpp_row_bcast<J>(qv[b + 7]));
+        }
+    } else {
+#pragma unroll
+        for (int b = 0; b < NB; b += 4) {
+            acc0 = min(min(acc0, c[b] ^ dpp_row_bcast<J>(qv[b])), c[b + 1] ^ dpp_row_bcast<J>(qv[b + 1]));
+            acc1 = min(min(acc1, c[b + 2] ^ dpp_row_bcast<J>(qv[b + 2])), c[b + 3] ^ dpp_row_bcast<J>(qv[b + 3]));
+        }
     }
-    const u64 mm = __ballot(min(acc0, acc1) == 0u);
+    const u64 mm = __ballot(min(min(acc0, acc1), min(acc2, acc3)) == 0u);
     if (mm && i < i_hi) {
         const int lo = max(i + 1, z0);
         const int hk = min(hi[i], n - 1);

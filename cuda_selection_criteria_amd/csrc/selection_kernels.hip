@@ -143,6 +143,7 @@ struct selhip_ctx {
     int n_chunks_last = 1;
     int pipeline = -1;                  // -1 auto, 0 off, >0 forced chunk count
     int il_block = 96, il_parts = 1, il_part = 0;    // row interleave (selhip_ctx_set_row_interleave); il_parts 1 = contiguous
+    int hist_run = 1, hist_blocks = kHistSpanBlocks;   // stage 2a: pairs per task, one-wave blocks (multiple of 8)
     int join_qt = 96;                   // query rows per signature-join block (multiple of 16); measured flat 48..192
     bool group_stage2 = true;           // bucket survivors by query row before stage 2a (hll_union_hist_runs_kernel)
 
@@ -615,9 +616,9 @@ int enqueue_pass(selhip_ctx* c) {
         for (u64 off = 0; off < final_cap; off += window) {
             {
                 TimerScope t(c, T_HIST);
-                if (grouped)
-                    hipLaunchKernelGGL(hll_union_hist_runs_kernel, dim3(2048), dim3(kBlock), 0, c->stream,
-                                       c->d_hll, final_list, final_count, final_cap, c->counts.p, off, window);
+                if (c->p == 14)
+                    hipLaunchKernelGGL(hll_union_hist_runs_kernel, dim3(c->hist_blocks), dim3(kWave), 0, c->stream,
+                                       c->d_hll, final_list, final_count, final_cap, c->counts.p, off, window, c->hist_run);
                 else
                     hipLaunchKernelGGL(hll_union_hist_kernel, dim3(2048), dim3(kBlock), 0, c->stream,
                                        c->d_hll, c->p, final_list, final_count, (u64)0, final_cap, c->counts.p, off, window);
@@ -780,6 +781,16 @@ int selhip_ctx_set_param(selhip_ctx* c, const char* name, int value) {
     if (!std::strcmp(name, "join_qt")) {
         if (value < 16 || value > 4096 || value % 16) { set_err(&c->err, "join_qt must be a multiple of 16 in [16, 4096]"); return SELHIP_E_BADARG; }
         c->join_qt = value;
+        return SELHIP_OK;
+    }
+    if (!std::strcmp(name, "hist_run")) {
+        if (value < 1 || value > 1024) { set_err(&c->err, "hist_run must be in [1, 1024]"); return SELHIP_E_BADARG; }
+        c->hist_run = value;
+        return SELHIP_OK;
+    }
+    if (!std::strcmp(name, "hist_blocks")) {
+        if (value < 8 || value > 65536 || value % 8) { set_err(&c->err, "hist_blocks must be a multiple of 8 in [8, 65536]"); return SELHIP_E_BADARG; }
+        c->hist_blocks = value;
         return SELHIP_OK;
     }
     set_err(&c->err, "unknown parameter '%s'", name);
