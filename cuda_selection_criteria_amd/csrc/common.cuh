@@ -23,9 +23,9 @@ struct PassCounters {
     u64 n_candidates;    // ALGO_SIG: signature-join candidates
     u64 n_aux_in;        // pairs handed to the auxiliary-HLL criterion (hll_a / hll_an)
     u64 n_final;         // pairs handed to the final HLL-14 Jaccard stage
+    u64 n_pre;           // ALGO_SIG, 16-bit join: pairs with an equal 16-bit band signature (filtered down to n_candidates)
     int z0p1;            // 1 + first rank with e != 0; 0 (the memset value) = none, i.e. z0 = n
     int unsorted;        // set if cards are not ascending
-    int pad[2];
 };
 
 

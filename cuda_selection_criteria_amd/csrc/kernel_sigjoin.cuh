@@ -22,10 +22,12 @@ __device__ __forceinline__ u64 mix64(u64 x) {
 
 // sig_build_kernel: one thread per bucket, coalesced 8-B loads; the r lanes of a band add their position-salted
 // mixes with xor-shuffles (r <= 64) -- or one thread walks the band (r > 64).  Writes both layouts:
-//   sigQ[g][NB] (query-major, read with scalar loads) and sigT[b][n_pad] (band-major, lane = candidate).
+//   sigQ[g][NB] (genome-major), sigT[b][n_pad] (band-major, lane = candidate) and sigP[b/2][n_pad]: the top 16 bits of
+//   the signatures of bands 2d (low half) and 2d+1 (high half) packed in one dword, for the 16-bit join.
 __global__ __launch_bounds__(kBlock)
 void sig_build_kernel(const u64* __restrict__ aux, int n, int m, int r, int nb, int n_pad,
-                      uint32_t* __restrict__ sigQ, uint32_t* __restrict__ sigT) {
+                      uint32_t* __restrict__ sigQ, uint32_t* __restrict__ sigT, uint32_t* __restrict__ sigP) {
+    uint16_t* const sigP16 = reinterpret_cast<uint16_t*>(sigP);
     if (r <= kWave) {
         const long long t = (long long)blockIdx.x * kBlock + threadIdx.x;      // global bucket index
         const long long total = (long long)n * m;
@@ -44,6 +46,7 @@ void sig_build_kernel(const u64* __restrict__ aux, int n, int m, int r, int nb, 
             const uint32_t sig = (uint32_t)(h ^ (h >> 32));
             sigQ[(long long)g * nb + b] = sig;
             sigT[(long long)b * n_pad + g] = sig;
+            sigP16[((long long)(b >> 1) * n_pad + g) * 2 + (b & 1)] = (uint16_t)(sig >> 16);
         }
     } else {
         const long long t = (long long)blockIdx.x * kBlock + threadIdx.x;      // (genome, band)
@@ -55,6 +58,7 @@ void sig_build_kernel(const u64* __restrict__ aux, int n, int m, int r, int nb, 
         const uint32_t sig = (uint32_t)(h ^ (h >> 32));
         sigQ[(long long)g * nb + b] = sig;
         sigT[(long long)b * n_pad + g] = sig;
+        sigP16[((long long)(b >> 1) * n_pad + g) * 2 + (b & 1)] = (uint16_t)(sig >> 16);
     }
 }
 
@@ -146,6 +150,101 @@ void sig_join_kernel(const uint32_t* __restrict__ sigT, int n, int n_pad,
     app.flush(lane);
 }
 
+// sig16_join_kernel<ND>: the same all-pairs join on 16-bit signatures packed two bands per dword (sigP): one band
+// compare is half a `v_xor_b32_dpp` plus half a `v_pk_min_u16` -- 1.0 instead of 1.5 VALU instructions per band -- and a
+// lane holds ND = NB/2 registers per side.  A zero 16-bit half of the running minimum = some band's 16-bit signature
+// equal: a superset (NB * 2^-16 per pair) of the 32-bit candidates, cut back to exactly that set by verify16_kernel.
+typedef unsigned short us2_t __attribute__((ext_vector_type(2)));
+
+template <int ND, int J>
+__device__ __forceinline__ void join16_one_query(const uint32_t (&c)[ND], const uint32_t (&qv)[ND], int i, int i_hi,
+                                                 int k, int lane, int z0, int n, const int* __restrict__ hi,
+                                                 WaveAppender& app) {
+    us2_t acc[4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) acc[a] = us2_t{0xFFFF, 0xFFFF};
+#pragma unroll
+    for (int d = 0; d < ND; d += 4) {
+        uint32_t x[4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a) x[a] = c[d + a] ^ dpp_row_bcast<J>(qv[d + a]);
+#pragma unroll
+        for (int a = 0; a < 4; ++a) acc[a] = __builtin_elementwise_min(acc[a], __builtin_bit_cast(us2_t, x[a]));
+    }
+    const uint32_t mv = __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_elementwise_min(acc[0], acc[1]),
+                                                                                 __builtin_elementwise_min(acc[2], acc[3])));
+    const u64 mm = __ballot(min(mv & 0xFFFFu, mv >> 16) == 0u);
+    if (mm && i < i_hi) {
+        const int lo = max(i + 1, z0);
+        const int hk = min(hi[i], n - 1);
+        app.push(((mm >> lane) & 1ull) && k >= lo && k <= hk, i, k, lane);
+    }
+}
+
+template <int ND, bool DB>
+__global__ __launch_bounds__(kBlock)
+void sig16_join_kernel(const uint32_t* __restrict__ sigP, int n, int n_pad,
+                       const int* __restrict__ hi, const PassCounters* __restrict__ pc_in,
+                       RowMap rm, int n_tiles, int group_base, int qt,
+                       selhip_int2_t* __restrict__ pre, u64 pre_cap, PassCounters* __restrict__ pc) {
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
+    const int tile = blockIdx.x % n_tiles;
+    const int grp = group_base + (blockIdx.x / n_tiles) * kWavesPerBlock + wave;
+    const int k_base = grp * kWave;
+    if (k_base >= n) return;
+    const int z0 = pc_in->z0p1 ? pc_in->z0p1 - 1 : n;
+    const int k_last = k_base + kWave - 1;
+    int i_lo, i_end;
+    rm.tile_rows(tile, qt, &i_lo, &i_end);                                    // qt is a multiple of 16
+    const int i_hi = min(i_end, k_last);                                      // need i < k for some lane
+    if (i_lo >= i_hi || k_last < z0) return;
+    if (hi[i_hi - 1] < k_base) return;                                        // hi is non-decreasing
+
+    __shared__ selhip_int2_t app_lds[kWavesPerBlock * kAppendCap];
+    WaveAppender app;
+    app.init(app_lds, wave, pre, pre_cap, &pc->n_pre);
+    const int k = k_base + lane;                                              // < n_pad
+    uint32_t c[ND];
+#pragma unroll
+    for (int d = 0; d < ND; ++d) c[d] = sigP[(long long)d * n_pad + k];
+
+#define SELHIP_JQ16(Q, I0) \
+    { join16_one_query<ND, 0>(c, Q, (I0) + 0, i_hi, k, lane, z0, n, hi, app); join16_one_query<ND, 1>(c, Q, (I0) + 1, i_hi, k, lane, z0, n, hi, app); \
+      join16_one_query<ND, 2>(c, Q, (I0) + 2, i_hi, k, lane, z0, n, hi, app); join16_one_query<ND, 3>(c, Q, (I0) + 3, i_hi, k, lane, z0, n, hi, app); \
+      join16_one_query<ND, 4>(c, Q, (I0) + 4, i_hi, k, lane, z0, n, hi, app); join16_one_query<ND, 5>(c, Q, (I0) + 5, i_hi, k, lane, z0, n, hi, app); \
+      join16_one_query<ND, 6>(c, Q, (I0) + 6, i_hi, k, lane, z0, n, hi, app); join16_one_query<ND, 7>(c, Q, (I0) + 7, i_hi, k, lane, z0, n, hi, app); \
+      join16_one_query<ND, 8>(c, Q, (I0) + 8, i_hi, k, lane, z0, n, hi, app); join16_one_query<ND, 9>(c, Q, (I0) + 9, i_hi, k, lane, z0, n, hi, app); \
+      join16_one_query<ND, 10>(c, Q, (I0) + 10, i_hi, k, lane, z0, n, hi, app); join16_one_query<ND, 11>(c, Q, (I0) + 11, i_hi, k, lane, z0, n, hi, app); \
+      join16_one_query<ND, 12>(c, Q, (I0) + 12, i_hi, k, lane, z0, n, hi, app); join16_one_query<ND, 13>(c, Q, (I0) + 13, i_hi, k, lane, z0, n, hi, app); \
+      join16_one_query<ND, 14>(c, Q, (I0) + 14, i_hi, k, lane, z0, n, hi, app); join16_one_query<ND, 15>(c, Q, (I0) + 15, i_hi, k, lane, z0, n, hi, app); }
+#define SELHIP_LOADQ(Q, I0) \
+    { const int qi_ = min((I0) + (lane & 15), n_pad - 1); \
+      _Pragma("unroll") for (int d = 0; d < ND; ++d) Q[d] = sigP[(long long)d * n_pad + qi_]; }
+
+    if constexpr (DB) {
+        // two register sets: the next 16 queries are in flight while the current 16 are compared
+        uint32_t qa[ND], qb[ND];
+        SELHIP_LOADQ(qa, i_lo)
+        for (int i16 = i_lo; i16 < i_hi; i16 += 32) {
+            SELHIP_LOADQ(qb, i16 + 16)
+            SELHIP_JQ16(qa, i16)
+            if (i16 + 16 >= i_hi) break;
+            SELHIP_LOADQ(qa, i16 + 32)
+            SELHIP_JQ16(qb, i16 + 16)
+        }
+    } else {
+        for (int i16 = i_lo; i16 < i_hi; i16 += 16) {
+            uint32_t qv[ND];
+            SELHIP_LOADQ(qv, i16)
+            SELHIP_JQ16(qv, i16)
+        }
+    }
+#undef SELHIP_JQ16
+#undef SELHIP_LOADQ
+    app.flush(lane);
+}
+
 // verify_kernel: the literal smh_a on every candidate (one lane per candidate), survivors compacted.
 __global__ __launch_bounds__(kBlock)
 void verify_kernel(const u64* __restrict__ aux, int m, int n_rows, int n_bands,
@@ -159,6 +258,118 @@ void verify_kernel(const u64* __restrict__ aux, int m, int n_rows, int n_bands,
             u64 idx = atomicAdd(&pc->n_survivors, 1ull);
             if (idx < surv_cap) surv[idx] = pr;
         }
+    }
+}
+
+// verify16_kernel: verification behind the 16-bit join.  A wave takes 64 pairs of the join's output at a time and works
+// on them four at a time, 16 lanes per pair (step s: quarter-wave q has pair 4s+q).
+//  1. 32-bit signatures: the lanes of a quarter read the two genomes' signature rows from the genome-major copy sigQ
+//     (coalesced 16-B loads, 2 x n_bands*4 bytes per pair, L2-resident) and keep one bit per band "32-bit signature
+//     equal".  Pairs with a bit set are exactly the candidate set of the 32-bit join (counted in n_candidates).
+//  2. A band that is entirely equal has an equal signature, so only bands with a bit set can make smh_a true: the first
+//     such band of each pair is compared on the full sketches (n_rows u64 per genome, 16 lanes).  Equal -> the pair
+//     survives.  Not equal (a 32-bit hash collision, ~2^-32 per band) -> the pair takes the literal smh_a on one lane.
+// All loads of a phase are independent across the steps, so a batch costs a handful of memory round trips instead of the
+// ~n_bands dependent ones of the lane-serial literal check (verify_kernel: 32 us for 45 000 candidates at cfg3).
+// Recorded alternatives: a separate filter kernel appending the passing pairs to a list (58 us at cfg3 -- one
+// single-address atomic per wave, ~85 of those per microsecond); one lane per pair for step 1 (uncoalesced loads: cfg4
+// verification 90 -> 370 us); literal check in place on each batch's few passing lanes (cfg4 355 us) or on lanes packed
+// through LDS (cfg4 205 us, cfg3 60 us).
+// Output: the survivors of a block's 1024 pairs are gathered in LDS and appended with ONE global atomic per block and
+// batch (plus one for the candidate tally): appends are single-address atomics, ~85 per microsecond on this part, and a
+// per-wave append (1 500 waves at cfg3) costs more than the whole check (52 us vs 15 us).
+// force_fallback (test hook): treat every first-band comparison as a collision.
+constexpr int kVerifyBlock = 1024;
+
+__global__ __launch_bounds__(kVerifyBlock)
+void verify16_kernel(const u64* __restrict__ aux, int m, int n_rows, int n_bands, const uint32_t* __restrict__ sigQ,
+                     const selhip_int2_t* __restrict__ pre, const u64* __restrict__ n_pre_dev, u64 pre_cap,
+                     selhip_int2_t* __restrict__ surv, u64 surv_cap, PassCounters* __restrict__ pc, int force_fallback) {
+    __shared__ selhip_int2_t out_lds[kVerifyBlock];
+    __shared__ uint32_t blk_count, blk_cand;
+    __shared__ u64 blk_base;
+    u64 n_pre = *n_pre_dev;
+    if (n_pre > pre_cap) n_pre = pre_cap;
+    const int lane = threadIdx.x & (kWave - 1);
+    const int sub = lane & 15, quarter = lane >> 4, qshift = quarter * 16;
+    const int nq = n_bands >> 2;                                              // 16-byte groups per genome (n_bands % 8 == 0, <= 32)
+    if (threadIdx.x == 0) { blk_count = 0; blk_cand = 0; }
+    __syncthreads();
+    for (u64 base = (u64)blockIdx.x * kVerifyBlock; base < n_pre; base += (u64)gridDim.x * kVerifyBlock) {
+        const u64 j = base + threadIdx.x;
+        const bool live = j < n_pre;
+        selhip_int2_t pr{0, 0};
+        if (live) pr = pre[j];
+        const u64 live_mask = __ballot(live);
+        u64 has_mask = 0, ok_mask = 0, fb_mask = 0;                           // bit p: pair p of this wave's 64 (wave-uniform)
+#pragma unroll 1
+        for (int s0 = 0; s0 < 16; s0 += 8) {
+            int px[8], py[8];
+            uint32_t lm[8];           // bit t (0..3): band 4*sub+t equal; bit 4+t: band 4*(sub+16)+t equal
+#pragma unroll
+            for (int s = 0; s < 8; ++s) {
+                const int src = (s0 + s) * 4 + quarter;
+                px[s] = __shfl(pr.x, src, kWave);
+                py[s] = __shfl(pr.y, src, kWave);
+                const uint4* a = reinterpret_cast<const uint4*>(sigQ + (long long)px[s] * n_bands);
+                const uint4* b = reinterpret_cast<const uint4*>(sigQ + (long long)py[s] * n_bands);
+                uint32_t bits = 0;
+                if (sub < nq) {
+                    const uint4 u = a[sub], v = b[sub];
+                    bits |= (u.x == v.x ? 1u : 0u) | (u.y == v.y ? 2u : 0u) | (u.z == v.z ? 4u : 0u) | (u.w == v.w ? 8u : 0u);
+                }
+                if (sub + 16 < nq) {
+                    const uint4 u = a[sub + 16], v = b[sub + 16];
+                    bits |= (u.x == v.x ? 16u : 0u) | (u.y == v.y ? 32u : 0u) | (u.z == v.z ? 64u : 0u) | (u.w == v.w ? 128u : 0u);
+                }
+                lm[s] = ((live_mask >> src) & 1ull) ? bits : 0u;
+            }
+#pragma unroll
+            for (int s = 0; s < 8; ++s) {
+                const uint32_t mine = (uint32_t)(__ballot(lm[s] != 0u) >> qshift) & 0xFFFFu;   // lanes of my quarter with a bit
+                const bool has = mine != 0u;
+                const int src_sub = has ? __builtin_ctz(mine) : 0;
+                const uint32_t lmv = (uint32_t)__shfl((int)lm[s], qshift + src_sub, kWave);
+                const int t = has ? __builtin_ctz(lmv) : 0;
+                const int band = t < 4 ? src_sub * 4 + t : (src_sub + 16) * 4 + (t - 4);
+                const u64* x = aux + (long long)px[s] * m + (long long)band * n_rows;
+                const u64* y = aux + (long long)py[s] * m + (long long)band * n_rows;
+                bool eq = true;
+                for (int j0 = sub; j0 < n_rows; j0 += 16)
+                    if (has) eq &= x[j0] == y[j0];
+                const bool all_eq = ((uint32_t)(__ballot(eq) >> qshift) & 0xFFFFu) == 0xFFFFu && !force_fallback;
+                // one bit per quarter (lanes 0, 16, 32, 48) -> bits 4(s0+s) .. 4(s0+s)+3 of the pair masks
+                const u64 mh = __ballot(has && sub == 0), mo = __ballot(has && all_eq && sub == 0);
+                const int sh = (s0 + s) * 4;
+                has_mask |= (((mh >> 0) & 1ull) | (((mh >> 16) & 1ull) << 1) | (((mh >> 32) & 1ull) << 2) | (((mh >> 48) & 1ull) << 3)) << sh;
+                ok_mask |= (((mo >> 0) & 1ull) | (((mo >> 16) & 1ull) << 1) | (((mo >> 32) & 1ull) << 2) | (((mo >> 48) & 1ull) << 3)) << sh;
+            }
+        }
+        fb_mask = has_mask & ~ok_mask;                                        // signature collision: the literal predicate decides
+        bool ok = (ok_mask >> lane) & 1ull;
+        if ((fb_mask >> lane) & 1ull) ok = smh_a_lane(aux + (long long)pr.x * m, aux + (long long)pr.y * m, n_rows, n_bands);
+        const u64 okb = __ballot(ok);
+        if (okb) {
+            uint32_t wbase = 0;
+            if (lane == 0) wbase = atomicAdd(&blk_count, (uint32_t)__popcll(okb));
+            wbase = (uint32_t)__builtin_amdgcn_readfirstlane((int)wbase);
+            if (ok) out_lds[wbase + (uint32_t)__popcll(okb & ((1ull << lane) - 1ull))] = pr;
+        }
+        if (lane == 0 && has_mask) atomicAdd(&blk_cand, (uint32_t)__popcll(has_mask));
+        __syncthreads();
+        const uint32_t cnt = blk_count;
+        if (threadIdx.x == 0) {
+            if (cnt) blk_base = atomicAdd(&pc->n_survivors, (u64)cnt);
+            if (blk_cand) atomicAdd(&pc->n_candidates, (u64)blk_cand);
+        }
+        __syncthreads();
+        if (threadIdx.x < cnt) {
+            const u64 dst = blk_base + threadIdx.x;
+            if (dst < surv_cap) surv[dst] = out_lds[threadIdx.x];
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) { blk_count = 0; blk_cand = 0; }
+        __syncthreads();
     }
 }
 

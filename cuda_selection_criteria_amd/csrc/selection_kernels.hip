@@ -129,7 +129,7 @@ struct selhip_ctx {
     DevBuf<uint8_t> own_aux_hll;
     int p_aux = 0;
     int criterion = 0;
-    DevBuf<uint32_t> sigQ, sigT;        // ALGO_SIG: band signatures, query-major / band-major
+    DevBuf<uint32_t> sigQ, sigT, sigP;  // ALGO_SIG: band signatures, genome-major / band-major / band-major 16-bit pairs
     DevBuf<u64> hj_keys_in, hj_keys_out;   // ALGO_HASHJOIN: (band << 32 | signature) keys, before / after the sort
     DevBuf<int> hj_vals_in, hj_vals_out;   //                genome ranks carried by the keys
     DevBuf<char> hj_tmp;                   //                rocPRIM temporary storage
@@ -144,6 +144,9 @@ struct selhip_ctx {
     int pipeline = -1;                  // -1 auto, 0 off, >0 forced chunk count
     int il_block = 96, il_parts = 1, il_part = 0;    // row interleave (selhip_ctx_set_row_interleave); il_parts 1 = contiguous
     int hist_run = 1, hist_blocks = kHistSpanBlocks;   // stage 2a: pairs per task, one-wave blocks (multiple of 8)
+    int verify_fb = 0;                  // test hook: force the collision fallback of verify16_kernel
+    int join_db = 1;                    // 16-bit join: double-buffered query batches
+    int join_bits = 16;                 // signature width of the all-pairs join: 16 (packed, + 32-bit filter) or 32
     int join_qt = 96;                   // query rows per signature-join block (multiple of 16); measured flat 48..192
     bool group_stage2 = true;           // bucket survivors by query row before stage 2a (hll_union_hist_runs_kernel)
 
@@ -320,13 +323,33 @@ hipError_t launch_join(selhip_ctx* c, const StageIO& io, int n_pad, int rb, int 
     return hipGetLastError();
 }
 
+template <int ND, bool DB>
+hipError_t launch_join16(selhip_ctx* c, const StageIO& io, int n_pad, int rb, int re) {
+    const int n = (int)c->n;
+    const int qt = c->join_qt;
+    const RowMap rm = row_map(c, rb, re);
+    const long long n_tiles_ll = rm.n_tiles(qt);
+    if (n_tiles_ll > 0x7FFFFFFFll) return hipErrorInvalidValue;
+    const int n_tiles = (int)n_tiles_ll;
+    const int group_base = ((rb + 1) / kWave / kWavesPerBlock) * kWavesPerBlock;      // candidates k > row_begin
+    const int n_groups = (n + kWave - 1) / kWave - group_base;
+    const int n_gblocks = (n_groups + kWavesPerBlock - 1) / kWavesPerBlock;
+    if (n_tiles <= 0 || n_gblocks <= 0) return hipSuccess;
+    const long long blocks = (long long)n_tiles * n_gblocks;
+    if (blocks > 0x7FFFFFFFll) return hipErrorInvalidValue;
+    hipLaunchKernelGGL((sig16_join_kernel<ND, DB>), dim3((unsigned)blocks), dim3(kBlock), 0, io.st,
+                       c->sigP.p, n, n_pad, c->hi.p, c->pc.p, rm, n_tiles, group_base, qt,
+                       io.cand, io.cap, io.pc);
+    return hipGetLastError();
+}
+
 hipError_t launch_sig_build(selhip_ctx* c, int n_rows, int n_bands) {
     const int n = (int)c->n;
     const int n_pad = ((n + kWave - 1) / kWave) * kWave;
     TimerScope t(c, T_SIGBUILD);
     const long long threads = n_rows <= kWave ? (long long)n * c->m : (long long)n * n_bands;
     hipLaunchKernelGGL(sig_build_kernel, dim3((unsigned)((threads + kBlock - 1) / kBlock)), dim3(kBlock), 0, c->stream,
-                       c->d_aux, n, c->m, n_rows, n_bands, n_pad, c->sigQ.p, c->sigT.p);
+                       c->d_aux, n, c->m, n_rows, n_bands, n_pad, c->sigQ.p, c->sigT.p, c->sigP.p);
     return hipGetLastError();
 }
 
@@ -335,7 +358,25 @@ hipError_t launch_stage1_sig(selhip_ctx* c, const StageIO& io, int n_rows, int n
     const int n = (int)c->n;
     const int n_pad = ((n + kWave - 1) / kWave) * kWave;
     hipError_t e = hipSuccess;
-    {
+    if (c->join_bits == 16) {
+        {
+            TimerScope t(c, T_JOIN, io.st);
+            switch (n_bands) {
+                case 8: e = c->join_db ? launch_join16<4, true>(c, io, n_pad, rb, re) : launch_join16<4, false>(c, io, n_pad, rb, re); break;
+                case 16: e = c->join_db ? launch_join16<8, true>(c, io, n_pad, rb, re) : launch_join16<8, false>(c, io, n_pad, rb, re); break;
+                case 32: e = c->join_db ? launch_join16<16, true>(c, io, n_pad, rb, re) : launch_join16<16, false>(c, io, n_pad, rb, re); break;
+                case 64: e = c->join_db ? launch_join16<32, true>(c, io, n_pad, rb, re) : launch_join16<32, false>(c, io, n_pad, rb, re); break;
+                case 128: e = c->join_db ? launch_join16<64, true>(c, io, n_pad, rb, re) : launch_join16<64, false>(c, io, n_pad, rb, re); break;
+                default: return hipErrorInvalidValue;
+            }
+        }
+        if (e != hipSuccess) return e;
+        // the 16-bit matches were staged in the candidate list; survivors go to the survivor list as usual
+        TimerScope t(c, T_VERIFY, io.st);
+        hipLaunchKernelGGL(verify16_kernel, dim3(512), dim3(kVerifyBlock), 0, io.st, c->d_aux, c->m, n_rows, n_bands, c->sigQ.p,
+                           io.cand, &io.pc->n_pre, io.cap, io.surv, io.cap, io.pc, c->verify_fb);
+        return hipGetLastError();
+    } else {
         TimerScope t(c, T_JOIN, io.st);
         switch (n_bands) {
             case 8: e = launch_join<8>(c, io, n_pad, rb, re); break;
@@ -664,6 +705,7 @@ int ensure_scratch(selhip_ctx* c, size_t surv_cap, size_t res_cap) {
         if (nb <= 128 || hash) {
             HIPCHK(&c->err, c->sigQ.ensure((size_t)c->n * nb));
             HIPCHK(&c->err, c->sigT.ensure(n_pad * nb));
+            HIPCHK(&c->err, c->sigP.ensure(n_pad * (size_t)((nb + 1) / 2)));
         }
         if (hash) {
             const size_t total = (size_t)c->n * nb;
@@ -739,7 +781,7 @@ void selhip_ctx_destroy(selhip_ctx* c) {
     c->own_hll.release(); c->own_aux.release(); c->own_cards.release();
     c->ecard.release(); c->hi.release(); c->pc.release(); c->surv.release();
     c->counts.release(); c->results.release(); c->self_pairs.release();
-    c->cand.release(); c->sigQ.release(); c->sigT.release(); c->fin.release(); c->own_aux_hll.release();
+    c->cand.release(); c->sigQ.release(); c->sigT.release(); c->sigP.release(); c->fin.release(); c->own_aux_hll.release();
     c->hj_keys_in.release(); c->hj_keys_out.release(); c->hj_vals_in.release(); c->hj_vals_out.release(); c->hj_tmp.release();
     c->csr_cnt.release(); c->csr_start.release(); c->grouped.release(); c->scan_tmp.release();
     if (c->h_pc) (void)hipHostFree(c->h_pc);
@@ -781,6 +823,13 @@ int selhip_ctx_set_param(selhip_ctx* c, const char* name, int value) {
     if (!std::strcmp(name, "join_qt")) {
         if (value < 16 || value > 4096 || value % 16) { set_err(&c->err, "join_qt must be a multiple of 16 in [16, 4096]"); return SELHIP_E_BADARG; }
         c->join_qt = value;
+        return SELHIP_OK;
+    }
+    if (!std::strcmp(name, "verify_fb")) { c->verify_fb = value != 0; return SELHIP_OK; }
+    if (!std::strcmp(name, "join_db")) { c->join_db = value != 0; return SELHIP_OK; }
+    if (!std::strcmp(name, "join_bits")) {
+        if (value != 16 && value != 32) { set_err(&c->err, "join_bits must be 16 or 32"); return SELHIP_E_BADARG; }
+        c->join_bits = value;
         return SELHIP_OK;
     }
     if (!std::strcmp(name, "hist_run")) {
@@ -940,6 +989,12 @@ int selhip_ctx_run_async(selhip_ctx* c, int mode, int algo, float tau_f, int n_r
     std::memset(&c->last, 0, sizeof c->last);
     if (c->n == 0 || row_begin == row_end) { c->pending = false; c->have_run = true; return SELHIP_OK; }
     size_t surv_cap = std::max<size_t>(c->surv.cap, std::max<size_t>((size_t)1 << 20, (size_t)c->n * 16));
+    if (needs_smh && c->join_bits == 16 && algo != SELHIP_ALGO_STREAM && algo != SELHIP_ALGO_HASHJOIN && sig_supported(c->m, n_rows, n_bands)) {
+        // the 16-bit join passes ~n_bands * 2^-16 of the pairs it compares on to the 32-bit filter: size the lists for that
+        // up front (an overflow would only cost one repeated pass)
+        const double expect = (double)pair_bound(c->n, (int)row_begin, (int)row_end) / std::max(1, c->il_parts) * n_bands / 65536.0;
+        surv_cap = std::max(surv_cap, (size_t)std::min(expect * 1.25 + 65536.0, (double)((size_t)1 << 26)));
+    }
     size_t res_cap = std::max<size_t>(c->results.cap, surv_cap);
     int rc = ensure_scratch(c, surv_cap, res_cap);
     if (rc) return rc;
@@ -965,7 +1020,7 @@ int selhip_ctx_finish(selhip_ctx* c) {
         for (int k = 1; k <= chunks; ++k) {
             const PassCounters& q = c->h_pc[k];
             pc.n_survivors += q.n_survivors; pc.n_candidates += q.n_candidates; pc.n_aux_in += q.n_aux_in; pc.n_final += q.n_final;
-            const u64 worst = std::max(std::max(q.n_survivors, q.n_candidates), c->criterion != SELHIP_CRIT_SMH_A ? q.n_final : 0);
+            const u64 worst = std::max(std::max(std::max(q.n_survivors, q.n_candidates), q.n_pre), c->criterion != SELHIP_CRIT_SMH_A ? q.n_final : 0);
             if (worst > slice) { surv_cap = std::max(surv_cap, (size_t)((worst + worst / 8 + 1024) * (u64)chunks)); grow = true; }
             if (q.n_aux_in > c->cand.cap) { c->pending = false; set_err(&c->err, "internal: enumerated pair list overflow"); return SELHIP_E_OVERFLOW; }
         }
