@@ -142,12 +142,12 @@ struct selhip_ctx {
     hipEvent_t ev_start = nullptr, ev_end = nullptr, ev_chunk[8] = {};
     int n_chunks_last = 1;
     int pipeline = -1;                  // -1 auto, 0 off, >0 forced chunk count
-    int il_block = 96, il_parts = 1, il_part = 0;    // row interleave (selhip_ctx_set_row_interleave); il_parts 1 = contiguous
+    int il_block = 128, il_parts = 1, il_part = 0;    // row interleave (selhip_ctx_set_row_interleave); il_parts 1 = contiguous
     int hist_run = 1, hist_blocks = kHistSpanBlocks;   // stage 2a: pairs per task, one-wave blocks (multiple of 8)
     int verify_fb = 0;                  // test hook: force the collision fallback of verify16_kernel
     int join_db = 1;                    // 16-bit join: double-buffered query batches
     int join_bits = 16;                 // signature width of the all-pairs join: 16 (packed, + 32-bit filter) or 32
-    int join_qt = 96;                   // query rows per signature-join block (multiple of 16); measured flat 48..192
+    int join_qt = 128;                  // query rows per signature-join block (multiple of 16); 16-bit join: 96..128 best at cfg3, 128..256 at cfg4
     bool group_stage2 = true;           // bucket survivors by query row before stage 2a (hll_union_hist_runs_kernel)
 
     // last run parameters (for overflow re-runs)
@@ -157,7 +157,9 @@ struct selhip_ctx {
     int64_t row_begin = 0, row_end = 0;
     PassCounters last{};
 
-    bool timing = false;
+    int timing = 0;                     // 0 off, 1 every kernel scope, 2 dominant stage-1 kernel only
+    int dominant_timer = T_STAGE1;
+    long timed_passes = 0;
     KernelTimer timers[T_COUNT];
 };
 
@@ -173,17 +175,20 @@ int check_device(std::string* err) {
     return SELHIP_OK;
 }
 
+// timing level 1: every scope; level 2: only the dominant stage-1 kernel (an event pair costs ~10 us of stream time, and a
+// pass of the default workload is ~0.4 ms)
 struct TimerScope {
-    selhip_ctx* c; int id; hipStream_t st; hipEvent_t a = nullptr, b = nullptr;
+    selhip_ctx* c; int id; hipStream_t st; hipEvent_t a = nullptr, b = nullptr; bool on;
     TimerScope(selhip_ctx* c_, int id_) : TimerScope(c_, id_, c_->stream) {}
     TimerScope(selhip_ctx* c_, int id_, hipStream_t st_) : c(c_), id(id_), st(st_) {
-        if (c->timing) {
+        on = c->timing == 1 || (c->timing == 2 && id == c->dominant_timer);
+        if (on) {
             (void)hipEventCreate(&a); (void)hipEventCreate(&b);
             (void)hipEventRecord(a, st);
         }
     }
     ~TimerScope() {
-        if (c->timing) {
+        if (on) {
             (void)hipEventRecord(b, st);
             c->timers[id].ev.emplace_back(a, b);
         }
@@ -533,6 +538,13 @@ int enqueue_pass(selhip_ctx* c) {
     const double tau = (double)c->tau_f;            // float threshold widened, selection.cpp:81,164
     const int crit = c->criterion;
     PassCounters* pc0 = c->pc.p;                    // block 0: z0, evaluated, results; blocks 1.. : one per row chunk
+    {
+        const bool smh = crit == SELHIP_CRIT_SMH_A || crit == SELHIP_CRIT_HLL_A_SMH_A;
+        const bool sig = smh && (c->algo == SELHIP_ALGO_HASHJOIN ||
+                                 ((c->algo == SELHIP_ALGO_SIG || c->algo == SELHIP_ALGO_AUTO) && sig_supported(c->m, c->n_rows, c->n_bands)));
+        c->dominant_timer = sig ? T_JOIN : T_STAGE1;
+        if (c->timing) c->timed_passes += 1;
+    }
     TimerScope total(c, T_TOTAL);
     HIPCHK(&c->err, hipMemsetAsync(c->pc.p, 0, sizeof(PassCounters) * (kMaxChunks + 1), c->stream));
     {
@@ -1117,13 +1129,14 @@ int selhip_ctx_timing(selhip_ctx* c, int enable) {
     (void)hipStreamSynchronize(c->stream);
     drain_timers(c);
     for (int t = 0; t < T_COUNT; ++t) { c->timers[t].total_ms = 0; c->timers[t].launches = 0; }
-    c->timing = enable != 0;
+    c->timing = enable == 2 ? 2 : (enable != 0 ? 1 : 0);
+    c->timed_passes = 0;
     return SELHIP_OK;
 }
 
 double selhip_ctx_kernel_ms(const selhip_ctx* c, const char* name) {
     if (!c || !name) return -1.0;
-    const long passes = c->timers[T_TOTAL].launches;
+    const long passes = c->timed_passes;
     for (int t = 0; t < T_COUNT; ++t)
         if (!std::strcmp(name, kTimerNames[t]))
             return (c->timers[t].launches && passes) ? c->timers[t].total_ms / (double)passes : -1.0;
@@ -1132,7 +1145,7 @@ double selhip_ctx_kernel_ms(const selhip_ctx* c, const char* name) {
 
 double selhip_ctx_kernel_launches(const selhip_ctx* c, const char* name) {
     if (!c || !name) return -1.0;
-    const long passes = c->timers[T_TOTAL].launches;
+    const long passes = c->timed_passes;
     for (int t = 0; t < T_COUNT; ++t)
         if (!std::strcmp(name, kTimerNames[t]))
             return passes ? (double)c->timers[t].launches / (double)passes : 0.0;
@@ -1355,7 +1368,7 @@ int selhip_multi_select(const int* devices, int n_devices,
             r = selhip_ctx_set_fp_mode(c, fp_mode);
             if (!r) r = selhip_ctx_upload(c, h_hll, h_aux, h_cards, n, m, p_hll);
             // interleaved row blocks: every device gets the same share of pairs and of survivors
-            if (!r) r = selhip_ctx_set_row_interleave(c, 96, G, g);
+            if (!r) r = selhip_ctx_set_row_interleave(c, 128, G, g);
             if (!r) r = selhip_ctx_run(c, mode, algo, tau_f, n_rows, n_bands, 0, n);
             if (!r) { counts[(size_t)g] = selhip_ctx_result_count(c); r = selhip_ctx_stats(c, st[(size_t)g].data()); }
             if (r) { rc[(size_t)g] = r; errs[(size_t)g] = selhip_last_error(c); }

@@ -229,8 +229,9 @@ class Selector:
         check(self._lib.selhip_ctx_stats(self._ctx, st), self._ctx)
         return {"evaluated": st[0], "survivors": st[1], "selected": st[2], "candidates": st[3]}
 
-    def timing(self, enable: bool = True):
-        check(self._lib.selhip_ctx_timing(self._ctx, 1 if enable else 0), self._ctx)
+    def timing(self, enable=True):
+        """False/0 = off, True/1 = every kernel scope, 2 = only the dominant stage-1 kernel (resets the figures)"""
+        check(self._lib.selhip_ctx_timing(self._ctx, int(enable)), self._ctx)
 
     def kernel_ms(self, name: str) -> float:
         """device ms per pass spent in the named kernel (sum over its launches of one pass)"""

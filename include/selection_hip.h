@@ -120,10 +120,16 @@ int selhip_ctx_set_pipeline(selhip_ctx* ctx, int chunks);
  * Every rank then gets the same share of the pair space AND of the survivors, whatever the triangle's shape (a contiguous
  * equal-pair cut hands the last of 8 ranks ~35 % of all rows, i.e. of all stage-2 work).  n_parts <= 1 switches it off. */
 int selhip_ctx_set_row_interleave(selhip_ctx* ctx, int block_rows, int n_parts, int part);
-/* Tunables (integers by name): "join_qt" = query rows per block of the signature join (multiple of 16, default 96). */
+/* Tunables (integers by name; results never depend on them):
+ *   "join_qt"     query rows per block of the signature join (multiple of 16, default 128)
+ *   "join_bits"   16 (default): all-pairs join on 16-bit band signatures packed two per dword, its matches cut back to the
+ *                 32-bit candidate set during verification; 32: join on the 32-bit signatures directly
+ *   "join_db"     1 (default) / 0: double-buffered query batches in the 16-bit join
+ *   "hist_run"    pairs a wave of stage 2a takes at a time (default 1);  "hist_blocks"  its one-wave blocks (multiple of 8)
+ *   "verify_fb"   test hook: 1 sends every candidate through the hash-collision fallback of the verification */
 int selhip_ctx_set_param(selhip_ctx* ctx, const char* name, int value);
 /* Stage 2 grouping (default on): the pairs that reach the HLL-14 stage are bucketed by query row (counting sort) so
- * that the histogram kernel reads a query row once per group instead of once per pair.  0 = off (ungrouped kernel). */
+ * that waves running side by side on one XCD share their query row in L2.  0 = off (same kernel, list as produced). */
 int selhip_ctx_set_stage2_grouping(selhip_ctx* ctx, int enable);
 /* SELHIP_FP_FMA (default) or SELHIP_FP_STRICT */
 int selhip_ctx_set_fp_mode(selhip_ctx* ctx, int fp_mode);
@@ -187,7 +193,10 @@ int selhip_ctx_copy_results_framed(selhip_ctx* ctx, void* d_dst, int64_t cap_rec
  * selhip_ctx_kernel_launches: launches of that kernel per pass. */
 double selhip_ctx_kernel_ms(const selhip_ctx* ctx, const char* name);
 double selhip_ctx_kernel_launches(const selhip_ctx* ctx, const char* name);
-int    selhip_ctx_timing(selhip_ctx* ctx, int enable);   /* enable/disable + reset event timing */
+/* enable: 0 = off, 1 = every kernel scope, 2 = only the dominant stage-1 kernel ("join" for the signature algorithms,
+ * "stage1" otherwise) -- an event pair costs ~10 us of stream time, so level 2 is what a throughput measurement leaves on.
+ * Every call resets the accumulated figures. */
+int    selhip_ctx_timing(selhip_ctx* ctx, int enable);
 
 /* ---------------------------------------------------------------------------------------------------
  * 2b. Multi-GPU entry taking a device list: ONE process, one host thread + one context per

@@ -27,7 +27,7 @@ def timeit(rows, label):
 print("N =", n, "world =", world)
 worst = 0
 for part in range(world):
-    sel.set_row_interleave(96, world, part)
+    sel.set_row_interleave(128, world, part)
     worst = max(worst, timeit((0, n), f"interleaved part {part}"))
 sel.set_row_interleave(0, 1, 0)
 bounds = D.shard_rows(n, world)

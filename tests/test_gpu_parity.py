@@ -242,6 +242,41 @@ def test_stage2_grouping_on_off(oracle):
             assert_same_pairs(sel.run(0.5, MODE_CB_SMH, r, b, rows=(17, 333)), want[(want["i"] >= 17) & (want["i"] < 333)])
 
 
+def test_join_and_histogram_variants(oracle):
+    """every switch of the signature path gives the oracle's pairs: 16-bit packed join (default) vs 32-bit join, single- vs
+    double-buffered query batches, the hash-collision fallback of the batched verification forced on every candidate,
+    and stage 2a with other task shapes / block counts"""
+    # (rows, bands): 2x32, 8x64, 4x128 (two 16-byte signature groups per lane), 8x16, 16x8 and 64x8 (bands longer than 16 rows)
+    for name, tau, shape in (("synth_spread_n600_m64", 0.5, None), ("synth_flat_n300_m512", 0.8, None), ("synth_flat_n300_m512", 0.5, None),
+                             ("synth_flat_n200_m128", 0.9, None), ("synth_flat_n200_m128", 0.5, (16, 8)), ("synth_flat_n300_m512", 0.5, (64, 8))):
+        cfg = make_golden.GOLDEN_SYNTH[name]
+        hll, aux, cards, _, _ = sorted_set(cfg, oracle)
+        r, b = shape or pkg.banding(cfg.m, tau)
+        assert b in (8, 16, 32, 64, 128)
+        want, st = oracle.select(hll, aux, cards, tau, r, b)
+        want_all, st_all = oracle.select(hll, aux, cards, tau, r, b, use_cb=False)
+        with Selector(0) as sel:
+            sel.upload(hll, aux, cards)
+            cand = None
+            for bits, db, fb in ((16, 1, 0), (16, 0, 0), (32, 0, 0), (16, 1, 1), (16, 0, 1)):
+                sel.set_param("join_bits", bits); sel.set_param("join_db", db); sel.set_param("verify_fb", fb)
+                assert_same_pairs(sel.run(tau, MODE_CB_SMH, r, b, algo=ALGO_SIG), want)
+                s = sel.stats()
+                assert s["evaluated"] == st["evaluated"] and s["survivors"] == st["survivors"]
+                assert_same_pairs(sel.run(tau, MODE_SMH, r, b, algo=ALGO_SIG), want_all)
+                s = sel.stats()
+                assert s["survivors"] == st_all["survivors"]
+                cand = s["candidates"] if cand is None else cand
+                assert s["candidates"] == cand          # the 32-bit candidate set is the same whichever join produced it
+            sel.set_param("join_bits", 16); sel.set_param("join_db", 1); sel.set_param("verify_fb", 0)
+            for run, blocks in ((1, 8), (3, 64), (8, 2048), (1024, 16384), (1, 16384)):
+                sel.set_param("hist_run", run); sel.set_param("hist_blocks", blocks)
+                assert_same_pairs(sel.run(tau, MODE_CB_SMH, r, b), want)
+            for bad in (("join_bits", 24), ("hist_blocks", 12), ("hist_run", 0), ("no_such_param", 1)):
+                with pytest.raises(pkg.SelhipError):
+                    sel.set_param(*bad)
+
+
 def test_edge_cases(oracle):
     cfg = SynthConfig("edge", 130, 128, 0.9, 77, n_sh_lo=5000, n_sh_hi=5000)
     hll, aux, cards, _, _ = sorted_set(cfg, oracle)
