@@ -428,10 +428,10 @@ hipError_t launch_select(bool fma, hipStream_t st, unsigned grid, const uint32_t
                          selhip_result_t* rf32, int* out_count, u64 chunk_off = 0, u64 chunk_len = ~0ull) {
     const double rs = relerr_scaled_for(p);
     if (fma)
-        hipLaunchKernelGGL((ertl_select_kernel<true, MODE>), dim3(grid), dim3(kWave), 0, st, counts, n_dev, n_host, cap,
+        hipLaunchKernelGGL((ertl_select_kernel<true, MODE>), dim3((grid + kWavesPerBlock - 1) / kWavesPerBlock), dim3(kBlock), 0, st, counts, n_dev, n_host, cap,
                            p, rs, est, pairs, ecard, tau, results, results_cap, pc, rf32, out_count, chunk_off, chunk_len);
     else
-        hipLaunchKernelGGL((ertl_select_kernel<false, MODE>), dim3(grid), dim3(kWave), 0, st, counts, n_dev, n_host, cap,
+        hipLaunchKernelGGL((ertl_select_kernel<false, MODE>), dim3((grid + kWavesPerBlock - 1) / kWavesPerBlock), dim3(kBlock), 0, st, counts, n_dev, n_host, cap,
                            p, rs, est, pairs, ecard, tau, results, results_cap, pc, rf32, out_count, chunk_off, chunk_len);
     return hipGetLastError();
 }
