@@ -11,6 +11,7 @@ namespace {
 //              the loop `break`s at the first failing k (selection.cpp:282-283); e is ascending so the
 //              predicate is monotone and the break is exactly "k <= hi(i)")
 //   z0       = first rank with e != 0  (`if(e2 == 0) continue`, selection.cpp:281)
+// It is the first kernel of a pass, so it also clears the per-row counters of the stage-2 grouping (saves a memset).
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ bool cb_pred(double tau, u64 e1, u64 e2) {
     double gamma = (double)e1 / (double)e2;      // criteria_sketch.hpp:47 (size_t -> double, IEEE divide)
@@ -19,9 +20,10 @@ __device__ __forceinline__ bool cb_pred(double tau, u64 e1, u64 e2) {
 
 __global__ void cb_bounds_kernel(const double* __restrict__ cards, int n, double tau, int use_cb,
                                  RowMap rm, u64* __restrict__ ecard, int* __restrict__ hi,
-                                 PassCounters* __restrict__ pc) {
+                                 PassCounters* __restrict__ pc, int* __restrict__ csr_zero) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
+    if (csr_zero) { csr_zero[i] = 0; csr_zero[n + i] = 0; }     // stage 2's per-row counters (count / fill cursors) for this pass
     double c = cards[i];
     u64 e1 = selhip::trunc_card(c);
     ecard[i] = e1;

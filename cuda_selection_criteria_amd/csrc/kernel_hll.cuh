@@ -130,6 +130,40 @@ void csr_fill_kernel(const selhip_int2_t* __restrict__ pairs, const u64* __restr
     }
 }
 
+// exclusive scan of the per-row counts for small N (one 1024-thread block, tiles of 4096): one launch instead of the
+// two of rocprim::exclusive_scan (look-back state init + scan); larger N goes to rocPRIM.
+constexpr int kSmallScanMax = 32768;
+__global__ __launch_bounds__(1024)
+void csr_scan_small_kernel(const int* __restrict__ cnt, int* __restrict__ start, int n) {
+    __shared__ int wave_sum[16];
+    __shared__ int carry_s;
+    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+    if (threadIdx.x == 0) carry_s = 0;
+    __syncthreads();
+    for (int base = 0; base < n; base += 4096) {
+        const int i0 = base + threadIdx.x * 4;
+        int v[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) v[t] = i0 + t < n ? cnt[i0 + t] : 0;
+        const int mine = v[0] + v[1] + v[2] + v[3];
+        int inc = mine;                                                     // inclusive scan inside the wave
+#pragma unroll
+        for (int s = 1; s < kWave; s <<= 1) { const int o = __shfl_up(inc, s, kWave); if (lane >= s) inc += o; }
+        if (lane == kWave - 1) wave_sum[wave] = inc;
+        __syncthreads();
+        int wbase = 0;
+        for (int w = 0; w < wave; ++w) wbase += wave_sum[w];
+        int total = 0;
+        for (int w = 0; w < 16; ++w) total += wave_sum[w];
+        int run = carry_s + wbase + inc - mine;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) { if (i0 + t < n) start[i0 + t] = run; run += v[t]; }
+        __syncthreads();
+        if (threadIdx.x == 0) carry_s += total;
+        __syncthreads();
+    }
+}
+
 // hll_union_hist_runs_kernel (p = 14): one wave per block with a lane-private [bin][lane] histogram (16 KiB of LDS).
 //  * block b works in the (b % 8)-th eighth of the list (round-robin block dispatch puts it on XCD b % 8) and the waves
 //    of an XCD stride through that eighth together, `run_len` (default 1) consecutive pairs at a time;

@@ -284,7 +284,8 @@ constexpr int kVerifyBlock = 1024;
 __global__ __launch_bounds__(kVerifyBlock)
 void verify16_kernel(const u64* __restrict__ aux, int m, int n_rows, int n_bands, const uint32_t* __restrict__ sigQ,
                      const selhip_int2_t* __restrict__ pre, const u64* __restrict__ n_pre_dev, u64 pre_cap,
-                     selhip_int2_t* __restrict__ surv, u64 surv_cap, PassCounters* __restrict__ pc, int force_fallback) {
+                     selhip_int2_t* __restrict__ surv, u64 surv_cap, PassCounters* __restrict__ pc, int force_fallback,
+                     int* __restrict__ row_cnt) {
     __shared__ selhip_int2_t out_lds[kVerifyBlock];
     __shared__ uint32_t blk_count, blk_cand;
     __shared__ u64 blk_base;
@@ -365,7 +366,9 @@ void verify16_kernel(const u64* __restrict__ aux, int m, int n_rows, int n_bands
         __syncthreads();
         if (threadIdx.x < cnt) {
             const u64 dst = blk_base + threadIdx.x;
-            if (dst < surv_cap) surv[dst] = out_lds[threadIdx.x];
+            const selhip_int2_t q = out_lds[threadIdx.x];
+            if (dst < surv_cap) surv[dst] = q;
+            if (row_cnt) atomicAdd(&row_cnt[q.x], 1);                        // stage 2 grouping: survivors per query row (csr_count)
         }
         __syncthreads();
         if (threadIdx.x == 0) { blk_count = 0; blk_cand = 0; }

@@ -203,6 +203,7 @@ struct StageIO {
     selhip_int2_t* surv;
     u64 cap;
     PassCounters* pc;
+    int* row_cnt = nullptr;     // if set, the producer of `surv` also tallies survivors per query row (stage-2 grouping)
 };
 
 void drain_timers(selhip_ctx* c) {
@@ -379,7 +380,7 @@ hipError_t launch_stage1_sig(selhip_ctx* c, const StageIO& io, int n_rows, int n
         // the 16-bit matches were staged in the candidate list; survivors go to the survivor list as usual
         TimerScope t(c, T_VERIFY, io.st);
         hipLaunchKernelGGL(verify16_kernel, dim3(512), dim3(kVerifyBlock), 0, io.st, c->d_aux, c->m, n_rows, n_bands, c->sigQ.p,
-                           io.cand, &io.pc->n_pre, io.cap, io.surv, io.cap, io.pc, c->verify_fb);
+                           io.cand, &io.pc->n_pre, io.cap, io.surv, io.cap, io.pc, c->verify_fb, io.row_cnt);
         return hipGetLastError();
     } else {
         TimerScope t(c, T_JOIN, io.st);
@@ -550,7 +551,8 @@ int enqueue_pass(selhip_ctx* c) {
     {
         TimerScope t(c, T_PREP);
         hipLaunchKernelGGL(cb_bounds_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream,
-                           c->d_cards, n, tau, c->mode == SELHIP_MODE_CB_SMH ? 1 : 0, row_map(c, rb, re), c->ecard.p, c->hi.p, pc0);
+                           c->d_cards, n, tau, c->mode == SELHIP_MODE_CB_SMH ? 1 : 0, row_map(c, rb, re), c->ecard.p, c->hi.p, pc0,
+                           (c->p == 14 && c->group_stage2) ? c->csr_cnt.p : nullptr);
         HIPCHK(&c->err, hipGetLastError());
     }
     const bool smh_crit = crit == SELHIP_CRIT_SMH_A || crit == SELHIP_CRIT_HLL_A_SMH_A;
@@ -609,6 +611,10 @@ int enqueue_pass(selhip_ctx* c) {
 
     // ---- single chunk: everything in order on the context's stream (counter block 1)
     StageIO io{c->stream, c->cand.p, c->surv.p, (u64)c->surv.cap, pc0 + 1};
+    // the survivors of the 16-bit signature path are the final list when smh_a is the only criterion: verify16_kernel
+    // then tallies them per query row itself (no csr_count launch)
+    const bool count_in_verify = crit == SELHIP_CRIT_SMH_A && use_sig && !use_hash && c->join_bits == 16 && c->p == 14 && c->group_stage2;
+    if (count_in_verify) io.row_cnt = c->csr_cnt.p;
     const selhip_int2_t* final_list = c->surv.p;
     const u64* final_count = &io.pc->n_survivors;
     u64 final_cap = (u64)c->surv.cap;
@@ -655,12 +661,19 @@ int enqueue_pass(selhip_ctx* c) {
         if (grouped) {
             // bucket the final list by query row so that stage 2a can keep that row in registers across its pairs
             TimerScope t(c, T_GROUP);
-            HIPCHK(&c->err, hipMemsetAsync(c->csr_cnt.p, 0, sizeof(int) * 2 * (size_t)n, c->stream));
-            hipLaunchKernelGGL(csr_count_kernel, dim3(512), dim3(kBlock), 0, c->stream, final_list, final_count, final_cap, c->csr_cnt.p);
-            HIPCHK(&c->err, hipGetLastError());
-            size_t tmp_bytes = c->scan_tmp.cap;
-            HIPCHK(&c->err, rocprim::exclusive_scan(c->scan_tmp.p, tmp_bytes, c->csr_cnt.p, c->csr_start.p, 0, (size_t)n,
-                                                    rocprim::plus<int>(), c->stream));
+            // (the counters were cleared by cb_bounds_kernel)
+            if (!count_in_verify) {
+                hipLaunchKernelGGL(csr_count_kernel, dim3(512), dim3(kBlock), 0, c->stream, final_list, final_count, final_cap, c->csr_cnt.p);
+                HIPCHK(&c->err, hipGetLastError());
+            }
+            if (n <= kSmallScanMax) {
+                hipLaunchKernelGGL(csr_scan_small_kernel, dim3(1), dim3(1024), 0, c->stream, c->csr_cnt.p, c->csr_start.p, n);
+                HIPCHK(&c->err, hipGetLastError());
+            } else {
+                size_t tmp_bytes = c->scan_tmp.cap;
+                HIPCHK(&c->err, rocprim::exclusive_scan(c->scan_tmp.p, tmp_bytes, c->csr_cnt.p, c->csr_start.p, 0, (size_t)n,
+                                                        rocprim::plus<int>(), c->stream));
+            }
             hipLaunchKernelGGL(csr_fill_kernel, dim3(512), dim3(kBlock), 0, c->stream, final_list, final_count, final_cap,
                                c->csr_start.p, c->csr_cnt.p + n, c->grouped.p);
             HIPCHK(&c->err, hipGetLastError());
