@@ -130,38 +130,29 @@ void csr_fill_kernel(const selhip_int2_t* __restrict__ pairs, const u64* __restr
     }
 }
 
-// exclusive scan of the per-row counts for small N (one 1024-thread block, tiles of 4096): one launch instead of the
-// two of rocprim::exclusive_scan (look-back state init + scan); larger N goes to rocPRIM.
+// exclusive scan of the per-row counts for small N: one 1024-thread block, thread t owns the contiguous slice
+// [t*E, (t+1)*E), E = ceil(N/1024) <= 32 -- one launch instead of the two of rocprim::exclusive_scan (look-back state
+// init + scan); larger N goes to rocPRIM.
 constexpr int kSmallScanMax = 32768;
 __global__ __launch_bounds__(1024)
 void csr_scan_small_kernel(const int* __restrict__ cnt, int* __restrict__ start, int n) {
     __shared__ int wave_sum[16];
-    __shared__ int carry_s;
     const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
-    if (threadIdx.x == 0) carry_s = 0;
+    const int per = (n + 1023) / 1024;
+    const int i0 = threadIdx.x * per, i1 = min(i0 + per, n);
+    int v[32];
+    int mine = 0;
+#pragma unroll
+    for (int t = 0; t < 32; ++t) { v[t] = (t < per && i0 + t < i1) ? cnt[i0 + t] : 0; mine += v[t]; }
+    int inc = mine;                                                         // inclusive scan inside the wave
+#pragma unroll
+    for (int s = 1; s < kWave; s <<= 1) { const int o = __shfl_up(inc, s, kWave); if (lane >= s) inc += o; }
+    if (lane == kWave - 1) wave_sum[wave] = inc;
     __syncthreads();
-    for (int base = 0; base < n; base += 4096) {
-        const int i0 = base + threadIdx.x * 4;
-        int v[4];
+    int run = inc - mine;
+    for (int w = 0; w < wave; ++w) run += wave_sum[w];
 #pragma unroll
-        for (int t = 0; t < 4; ++t) v[t] = i0 + t < n ? cnt[i0 + t] : 0;
-        const int mine = v[0] + v[1] + v[2] + v[3];
-        int inc = mine;                                                     // inclusive scan inside the wave
-#pragma unroll
-        for (int s = 1; s < kWave; s <<= 1) { const int o = __shfl_up(inc, s, kWave); if (lane >= s) inc += o; }
-        if (lane == kWave - 1) wave_sum[wave] = inc;
-        __syncthreads();
-        int wbase = 0;
-        for (int w = 0; w < wave; ++w) wbase += wave_sum[w];
-        int total = 0;
-        for (int w = 0; w < 16; ++w) total += wave_sum[w];
-        int run = carry_s + wbase + inc - mine;
-#pragma unroll
-        for (int t = 0; t < 4; ++t) { if (i0 + t < n) start[i0 + t] = run; run += v[t]; }
-        __syncthreads();
-        if (threadIdx.x == 0) carry_s += total;
-        __syncthreads();
-    }
+    for (int t = 0; t < 32; ++t) { if (t < per && i0 + t < i1) start[i0 + t] = run; run += v[t]; }
 }
 
 // hll_union_hist_runs_kernel (p = 14): one wave per block with a lane-private [bin][lane] histogram (16 KiB of LDS).
@@ -171,6 +162,8 @@ void csr_scan_small_kernel(const int* __restrict__ cnt, int* __restrict__ start,
 //    puts lane*4 in byte 0 and the bin in byte 1 of the address, and `v_max_u32_sdwa dst_sel:BYTE_1
 //    dst_unused:UNUSED_PRESERVE` writes max(byte_s(x), byte_s(y)) straight into byte 1 of a register that keeps lane*4
 //    (the compiler's own sequence -- max, shift, mask, add -- is kept as the path for a histogram not at offset 0);
+//  * (binning a pair in two halves with the other half's loads in flight -- same registers, no wait on memory inside a
+//    wave -- changed nothing at cfg3 and cost 10 % at cfg4: the kernel waits on the LDS, not on memory);
 //  * the histogram is zeroed once per wave: bins only grow, and a pair's counts are the difference of the running column
 //    sums before and after it (unsigned arithmetic: wrap-around cancels), which removes 64 LDS stores per pair.
 constexpr int kHistSpanBlocks = 16384;      // one-wave blocks (a multiple of 8); ~8 resident per CU, the rest balance the tail
@@ -393,36 +386,74 @@ void enum_pairs_kernel(int n, const int* __restrict__ hi, const PassCounters* __
 //   CRIT 2 (hll_an): J = ((double)(e_i+e_k) - U)/U;  C = min(1, (1+Z*sigma_p)*e_k/U) * (1+gamma) * S;  J + C >= tau
 // zs = (double)(float)(Z*sigma_p) and S (= zs for order_n = 1) are computed on the host in float/double exactly as
 // criteria_sketch.hpp:7-20,25-31,39-40 do.  FMA flavour: g++ fuses (1+gamma)*card_B - t_hat_mas (criteria_sketch.hpp:41).
+struct LdsColumn {
+    const uint32_t* base;       // &hist[lane]
+    __device__ __forceinline__ uint32_t operator[](int k) const { return base[k * kWave]; }
+};
+
+// One LANE per pair, histogram and estimator fused: the auxiliary sketches are small (2^p_aux <= 4096 registers), so a lane
+// reads its pair's two rows itself (16-B loads), bins the per-byte max into ITS column of the wave's [bin][lane] LDS
+// histogram (one ds_add_u32 per register for 64 pairs at once, same one-instruction address formation as stage 2a) and
+// runs the estimator straight from that column -- no counts buffer, no second kernel.  (The earlier form -- one WAVE per
+// pair in hll_union_hist_kernel, 128 LDS operations of zeroing and reduction around 4 useful adds at p_aux = 8, then
+// aux_filter_kernel on the 256-B histograms -- took 0.89 ms of cfg5's pass.)
 template <bool FMA, int CRIT>
 __global__ __launch_bounds__(kWave)
-void aux_filter_kernel(const uint32_t* __restrict__ counts, const selhip_int2_t* __restrict__ pairs,
-                       const u64* __restrict__ n_dev, u64 chunk_off, u64 chunk_len, u64 cap,
-                       int p_aux, double relerr_scaled, const u64* __restrict__ ecard, double tau,
-                       double zs, double S_sum,
-                       selhip_int2_t* __restrict__ out, u64 out_cap, u64* __restrict__ out_count) {
-    __shared__ uint32_t lds[64 * 65];
+void aux_fused_kernel(const uint8_t* __restrict__ aux_hll, int p_aux, const selhip_int2_t* __restrict__ pairs,
+                      const u64* __restrict__ n_dev, u64 cap, double relerr_scaled, const u64* __restrict__ ecard, double tau,
+                      double zs, double S_sum,
+                      selhip_int2_t* __restrict__ out, u64 out_cap, u64* __restrict__ out_count) {
+    __shared__ __attribute__((aligned(16))) uint32_t hist[64 * kWave];     // declared first: LDS offset 0 (fast address path)
     __shared__ selhip_int2_t app_lds[kAppendCap];
     const int lane = threadIdx.x;
-    u64 total = *n_dev;
-    if (total > cap) total = cap;
-    const u64 n = total > chunk_off ? min(total - chunk_off, chunk_len) : 0;     // pairs of this chunk
+    u64 n = *n_dev;
+    if (n > cap) n = cap;
+    const long long nreg = 1ll << p_aux;
+    const int n16 = (int)(nreg >> 4);                                        // 16-byte groups per row (p_aux >= 4)
+    const bool lds_at_zero = (uint32_t)(uintptr_t)hist == 0u;
+    uint32_t* const col = hist + lane;
+    uint32_t a0 = (uint32_t)lane * 4u, a1 = a0, a2 = a0, a3 = a0;
+    constexpr uint32_t kMask = 0x3F3F3F3Fu;
     WaveAppender app;
     app.init(app_lds, 0, out, out_cap, out_count);
     for (u64 base = (u64)blockIdx.x * kWave; base < n; base += (u64)gridDim.x * kWave) {
-        __syncthreads();
-        for (int r = 0; r < kWave; ++r) {
-            u64 j = base + r;
-            lds[lane * 65 + r] = (j < n) ? counts[j * 64 + lane] : (lane == 0 ? (1u << p_aux) : 0u);
-        }
-        __syncthreads();
         const u64 j = base + lane;
-        LdsCounts c{lds + lane};
+        const bool live = j < n;
+        selhip_int2_t pr{0, 0};
+        u64 ea = 0, eb = 1;
+        if (live) { pr = pairs[j]; ea = ecard[pr.x]; eb = ecard[pr.y]; }
+#pragma unroll 8
+        for (int k = 0; k < 64; ++k) col[k * kWave] = 0;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        const uint4* ra = reinterpret_cast<const uint4*>(aux_hll + (long long)pr.x * nreg);
+        const uint4* rb = reinterpret_cast<const uint4*>(aux_hll + (long long)pr.y * nreg);
+        for (int c0 = 0; c0 < n16; c0 += 8) {                                // wave-uniform trip count
+            uint4 xa[8], xb[8];
+#pragma unroll
+            for (int t = 0; t < 8; ++t)
+                if (c0 + t < n16) { xa[t] = ra[c0 + t]; xb[t] = rb[c0 + t]; }
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                if (c0 + t < n16) {
+                    if (lds_at_zero) {
+                        hist_add_max_word(a0, a1, a2, a3, xa[t].x & kMask, xb[t].x & kMask);
+                        hist_add_max_word(a0, a1, a2, a3, xa[t].y & kMask, xb[t].y & kMask);
+                        hist_add_max_word(a0, a1, a2, a3, xa[t].z & kMask, xb[t].z & kMask);
+                        hist_add_max_word(a0, a1, a2, a3, xa[t].w & kMask, xb[t].w & kMask);
+                    } else {
+                        hist_add_word(col, max_u8x4(xa[t].x, xb[t].x));
+                        hist_add_word(col, max_u8x4(xa[t].y, xb[t].y));
+                        hist_add_word(col, max_u8x4(xa[t].z, xb[t].z));
+                        hist_add_word(col, max_u8x4(xa[t].w, xb[t].w));
+                    }
+                }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        LdsColumn c{col};
         const double U = selhip::ertl_ml_estimate<FMA>(c, (unsigned)p_aux, (unsigned)(64 - p_aux), relerr_scaled);
         bool sel = false;
-        selhip_int2_t pr{0, 0};
-        if (j < n) {
-            pr = pairs[chunk_off + j];
-            const u64 ea = ecard[pr.x], eb = ecard[pr.y];
+        if (live) {
             const double gamma = (double)ea / (double)eb;                         // criteria_sketch.hpp:24,38
             if constexpr (CRIT == 1) {
                 const double t_hat = (double)(u64)(long long)U;                   // size_t t_hat = union_size()  (:61)
@@ -437,6 +468,7 @@ void aux_filter_kernel(const uint32_t* __restrict__ counts, const selhip_int2_t*
                 sel = (J + C) >= tau;                                             // :57
             }
         }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         app.push(sel, pr.x, pr.y, lane);
     }
     app.flush(lane);

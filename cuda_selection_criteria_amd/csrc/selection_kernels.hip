@@ -480,20 +480,20 @@ long long pair_bound(long long n, long long rb, long long re) {
 }
 
 template <int CRIT>
-hipError_t launch_aux_filter(selhip_ctx* c, const selhip_int2_t* list, const u64* n_dev, u64 off, u64 len, u64 cap, double tau,
-                             u64* out_count) {
+hipError_t launch_aux_fused(selhip_ctx* c, const selhip_int2_t* list, const u64* n_dev, u64 cap, u64 bound, double tau,
+                            u64* out_count) {
     const float Z = 1.96f;                                   // z_score, selection.cpp:76
     const float zs_f = Z * sigma_p_of(c->p_aux);             // float * float (criteria_sketch.hpp:29,40)
     const double zs = (double)zs_f;
     const double S_sum = zs;                                 // order_n = 1 (selection.cpp:77): S = Z*sigma_p
     const double rs = relerr_scaled_for(c->p_aux);
-    const unsigned grid = 2048;
+    const unsigned grid = grid_for(bound, kWave, 32768);
     if (c->fp_mode == SELHIP_FP_FMA)
-        hipLaunchKernelGGL((aux_filter_kernel<true, CRIT>), dim3(grid), dim3(kWave), 0, c->stream, c->counts.p, list, n_dev, off, len, cap,
-                           c->p_aux, rs, c->ecard.p, tau, zs, S_sum, c->fin.p, (u64)c->fin.cap, out_count);
+        hipLaunchKernelGGL((aux_fused_kernel<true, CRIT>), dim3(grid), dim3(kWave), 0, c->stream, c->d_aux_hll, c->p_aux, list, n_dev, cap,
+                           rs, c->ecard.p, tau, zs, S_sum, c->fin.p, (u64)c->fin.cap, out_count);
     else
-        hipLaunchKernelGGL((aux_filter_kernel<false, CRIT>), dim3(grid), dim3(kWave), 0, c->stream, c->counts.p, list, n_dev, off, len, cap,
-                           c->p_aux, rs, c->ecard.p, tau, zs, S_sum, c->fin.p, (u64)c->fin.cap, out_count);
+        hipLaunchKernelGGL((aux_fused_kernel<false, CRIT>), dim3(grid), dim3(kWave), 0, c->stream, c->d_aux_hll, c->p_aux, list, n_dev, cap,
+                           rs, c->ecard.p, tau, zs, S_sum, c->fin.p, (u64)c->fin.cap, out_count);
     return hipGetLastError();
 }
 
@@ -635,21 +635,15 @@ int enqueue_pass(selhip_ctx* c) {
             HIPCHK(&c->err, hipGetLastError());
         }
     }
-    // ---- auxiliary-HLL criterion (hll_a / hll_an), in windows of the counts buffer
+    // ---- auxiliary-HLL criterion (hll_a / hll_an): histogram + estimator + test fused, one lane per pair
     if (crit != SELHIP_CRIT_SMH_A) {
         TimerScope t(c, T_AUX);
         const selhip_int2_t* list = crit == SELHIP_CRIT_HLL_A_SMH_A ? c->surv.p : c->cand.p;
         const u64* n_dev = crit == SELHIP_CRIT_HLL_A_SMH_A ? &io.pc->n_survivors : &io.pc->n_aux_in;
         const u64 cap = crit == SELHIP_CRIT_HLL_A_SMH_A ? (u64)c->surv.cap : (u64)c->cand.cap;
-        const u64 window = (u64)c->counts.cap / 64;
         const u64 bound = crit == SELHIP_CRIT_HLL_A_SMH_A ? cap : std::min<u64>(cap, (u64)pair_bound(n, rb, re));
-        for (u64 off = 0; off < bound; off += window) {
-            hipLaunchKernelGGL(hll_union_hist_kernel, dim3(2048), dim3(kBlock), 0, c->stream,
-                               c->d_aux_hll, c->p_aux, list, n_dev, (u64)0, cap, c->counts.p, off, window);
-            HIPCHK(&c->err, hipGetLastError());
-            if (crit == SELHIP_CRIT_HLL_AN) HIPCHK(&c->err, launch_aux_filter<2>(c, list, n_dev, off, window, cap, tau, &io.pc->n_final));
-            else                            HIPCHK(&c->err, launch_aux_filter<1>(c, list, n_dev, off, window, cap, tau, &io.pc->n_final));
-        }
+        if (crit == SELHIP_CRIT_HLL_AN) HIPCHK(&c->err, launch_aux_fused<2>(c, list, n_dev, cap, bound, tau, &io.pc->n_final));
+        else                            HIPCHK(&c->err, launch_aux_fused<1>(c, list, n_dev, cap, bound, tau, &io.pc->n_final));
         final_list = c->fin.p;
         final_count = &io.pc->n_final;
         final_cap = (u64)c->fin.cap;
