@@ -77,6 +77,8 @@ HIP_SYMBOLS = {
     "selhip_ctx_result_device": (_i, [_vp, C.POINTER(_vp), C.POINTER(_i64)]),
     "selhip_ctx_copy_results": (_i, [_vp, _vp, _i64]),
     "selhip_ctx_copy_results_framed": (_i, [_vp, _vp, _i64]),
+    "selhip_ctx_copy_results_framed_async": (_i, [_vp, _vp, _i64]),
+    "selhip_ctx_last_attempts": (_i, [_vp]),
     "selhip_ctx_kernel_ms": (_d, [_vp, _cp]),
     "selhip_ctx_kernel_launches": (_d, [_vp, _cp]),
     "selhip_ctx_timing": (_i, [_vp, _i]),

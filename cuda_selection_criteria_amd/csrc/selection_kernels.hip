@@ -160,6 +160,7 @@ struct selhip_ctx {
     int timing = 0;                     // 0 off, 1 every kernel scope, 2 dominant stage-1 kernel only
     int dominant_timer = T_STAGE1;
     long timed_passes = 0;
+    int last_attempts = 0;              // enqueues the last finished run needed (1 = nothing overflowed)
     KernelTimer timers[T_COUNT];
 };
 
@@ -1045,7 +1046,7 @@ int selhip_ctx_finish(selhip_ctx* c) {
         }
         if (pc.n_results > c->results.cap) { res_cap = (size_t)(pc.n_results + pc.n_results / 8 + 1024); grow = true; }
         if (!grow) {
-            c->last = pc; c->pending = false; c->have_run = true;
+            c->last = pc; c->pending = false; c->have_run = true; c->last_attempts = attempt + 1;
             if (c->timing) drain_timers(c);
             return SELHIP_OK;
         }
@@ -1130,6 +1131,21 @@ int selhip_ctx_copy_results_framed(selhip_ctx* c, void* d_dst, int64_t cap_recor
                                        hipMemcpyDeviceToDevice, c->stream));
     return (int64_t)c->last.n_results > cap_records ? SELHIP_E_OVERFLOW : SELHIP_OK;
 }
+
+int selhip_ctx_copy_results_framed_async(selhip_ctx* c, void* d_dst, int64_t cap_records) {
+    if (!c || !d_dst || cap_records < 0) return SELHIP_E_BADARG;
+    if (!c->pending && !c->have_run) return SELHIP_E_STATE;
+    if (!c->results.p || !c->pc.p) return SELHIP_E_STATE;
+    HIPCHK(&c->err, hipSetDevice(c->device));
+    HIPCHK(&c->err, hipMemcpyAsync(d_dst, &c->pc.p->n_results, sizeof(u64), hipMemcpyDeviceToDevice, c->stream));
+    const int64_t cnt = std::min<int64_t>((int64_t)c->results.cap, cap_records);
+    if (cnt > 0)
+        HIPCHK(&c->err, hipMemcpyAsync((char*)d_dst + sizeof(selhip_pair_t), c->results.p, (size_t)cnt * sizeof(selhip_pair_t),
+                                       hipMemcpyDeviceToDevice, c->stream));
+    return SELHIP_OK;
+}
+
+int selhip_ctx_last_attempts(const selhip_ctx* c) { return c ? c->last_attempts : SELHIP_E_BADARG; }
 
 int selhip_ctx_timing(selhip_ctx* c, int enable) {
     if (!c) return SELHIP_E_BADARG;

@@ -224,6 +224,16 @@ class Selector:
             check(rc, self._ctx)
         return self.result_count()
 
+    def copy_results_framed_async(self, tensor):
+        """the same frame enqueued behind a pass that is still running (between run_async and finish): header from the
+        device-side counter, payload = the whole capacity of `tensor`; check result_count() and last_attempts() after finish"""
+        cap = tensor.numel() * tensor.element_size() // PAIR_DTYPE.itemsize - 1
+        check(self._lib.selhip_ctx_copy_results_framed_async(self._ctx, tensor.data_ptr(), cap), self._ctx)
+        return cap
+
+    def last_attempts(self) -> int:
+        return int(check(self._lib.selhip_ctx_last_attempts(self._ctx), self._ctx))
+
     def stats(self) -> dict:
         st = (C.c_int64 * 4)()
         check(self._lib.selhip_ctx_stats(self._ctx, st), self._ctx)

@@ -186,6 +186,15 @@ int selhip_ctx_copy_results(selhip_ctx* ctx, selhip_pair_t* d_dst, int64_t cap);
 /* same, framed for a fixed-size collective: d_dst[0] = 16-byte header {u64 count, u64 0}, records from d_dst + 16;
  * d_dst must hold cap_records + 1 records.  Returns SELHIP_E_OVERFLOW (after copying cap_records) if count > cap. */
 int selhip_ctx_copy_results_framed(selhip_ctx* ctx, void* d_dst, int64_t cap_records);
+/* The same frame, enqueued BEHIND a pass that is still running (between selhip_ctx_run_async and selhip_ctx_finish), so
+ * that the caller can also enqueue its collective before it waits: the count is not known on the host yet, so the header
+ * is copied from the device-side counter and the payload copy always moves cap_records records (<= the result
+ * capacity).  After selhip_ctx_finish the caller checks selhip_ctx_result_count() <= cap_records and
+ * selhip_ctx_last_attempts() == 1 (an overflowing internal list makes finish repeat the pass, which would leave the
+ * frame stale) and otherwise frames again. */
+int selhip_ctx_copy_results_framed_async(selhip_ctx* ctx, void* d_dst, int64_t cap_records);
+/* number of times the last finished run had to enqueue its pass (1 = no internal list overflowed) */
+int selhip_ctx_last_attempts(const selhip_ctx* ctx);
 
 /* device time (ms, HIP events on the stream each kernel is launched on) of the named kernel PER PASS, averaged over
  * the passes since the last reset (a pipelined pass launches a kernel once per row chunk: the figure is their sum);

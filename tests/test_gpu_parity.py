@@ -488,6 +488,49 @@ def test_attach_device_tensors_and_sorted_generation(oracle):
     assert len(got) > 100
 
 
+def test_result_frames_on_the_device(oracle):
+    """the device-side result hand-over used for the RCCL gather: copy_results_to, the framed copy after finish, and the
+    framed copy enqueued behind a pass that is still running (count taken from the device-side counter)"""
+    import torch
+    cfg = make_golden.GOLDEN_SYNTH["synth_flat_n300_m512"]
+    hll, aux, cards, _, _ = sorted_set(cfg, oracle)
+    r, b = pkg.banding(cfg.m, 0.8)
+    want, _ = oracle.select(hll, aux, cards, 0.8, r, b)
+    assert len(want) > 10
+
+    def unpack(frame):
+        rec = frame.cpu().numpy()
+        cnt = int(rec[0, 0])
+        got = rec[1:1 + cnt].reshape(-1).view(pkg.PAIR_DTYPE)
+        return got[np.lexsort((got["k"], got["i"]))]
+
+    with Selector(0) as sel:
+        sel.upload(hll, aux, cards)
+        sel.run(0.8, MODE_CB_SMH, r, b, fetch=False)
+        cap = len(want) + 7
+        frame = torch.zeros((cap + 1, 2), dtype=torch.int64, device="cuda:0")
+        assert sel.copy_results_framed(frame) == len(want)
+        torch.cuda.synchronize()
+        assert_same_pairs(unpack(frame), want)
+        flat = torch.zeros((cap, 2), dtype=torch.int64, device="cuda:0")
+        assert sel.copy_results_to(flat) == len(want)
+        # behind a running pass
+        frame2 = torch.zeros((cap + 1, 2), dtype=torch.int64, device="cuda:0")
+        sel.run_async(0.8, MODE_CB_SMH, r, b)
+        sel.copy_results_framed_async(frame2)
+        sel.finish()
+        assert sel.last_attempts() == 1 and sel.result_count() == len(want)
+        torch.cuda.synchronize()
+        assert_same_pairs(unpack(frame2), want)
+        # a frame that is too small reports the true count in its header; the caller sees count > capacity
+        small = torch.zeros((4, 2), dtype=torch.int64, device="cuda:0")
+        sel.run_async(0.8, MODE_CB_SMH, r, b)
+        sel.copy_results_framed_async(small)
+        sel.finish()
+        torch.cuda.synchronize()
+        assert int(small.cpu().numpy()[0, 0]) == len(want) and sel.result_count() > 3
+
+
 def test_unsorted_cards_rejected(oracle):
     cfg = SynthConfig("unsorted", 50, 128, 0.9, 5, n_sh_lo=3000, n_sh_hi=3000)
     hll, aux, cards, _, _ = sorted_set(cfg, oracle)
