@@ -381,7 +381,7 @@ void enum_pairs_kernel(int n, const int* __restrict__ hi, const PassCounters* __
     app.flush(lane);
 }
 
-// aux_filter_kernel<FMA, CRIT>: one LANE per pair; counts = union histogram of the two AUXILIARY sketches.
+// aux_fused_kernel<FMA, CRIT>: one LANE per pair; U = Ertl-MLE of the union histogram of the two AUXILIARY sketches.
 //   CRIT 1 (hll_a):  t_hat = (size_t)U;  t+ = t_hat / (1 + Z*sigma_p);  K+ = ((1+gamma)*e_k - t+)/t+ >= tau
 //   CRIT 2 (hll_an): J = ((double)(e_i+e_k) - U)/U;  C = min(1, (1+Z*sigma_p)*e_k/U) * (1+gamma) * S;  J + C >= tau
 // zs = (double)(float)(Z*sigma_p) and S (= zs for order_n = 1) are computed on the host in float/double exactly as

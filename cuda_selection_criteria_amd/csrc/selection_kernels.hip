@@ -12,7 +12,7 @@
 //   kernel_stream.cuh   smh_stream_kernel     stage 1 ALGO_STREAM: query tile in LDS/VGPRs, candidates streamed row-major,
 //                                             v_cmp_eq_u64 lane masks folded on the scalar unit; smh_generic_kernel
 //   kernel_sigjoin.cuh  sig_build / sig_join / verify   stage 1 ALGO_SIG: all-pairs band-signature join (DPP broadcast) + exact verify
-//   kernel_hll.cuh      hll_union_hist_kernel, ertl_select_kernel (stage 2), enum_pairs / aux_filter (hll_a, hll_an)
+//   kernel_hll.cuh      hll_union_hist_kernel, ertl_select_kernel (stage 2), enum_pairs / aux_fused (hll_a, hll_an)
 //   kernel_pairlist.cuh explicit pair lists (drop-in launch_kernel_* path, test building blocks)
 //   kernel_sketch.cuh   synth_kernel, sketch_build_kernel (build_sketch on the GPU), permute_rows
 //
