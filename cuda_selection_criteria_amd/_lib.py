@@ -83,6 +83,9 @@ HIP_SYMBOLS = {
     "selhip_ctx_kernel_launches": (_d, [_vp, _cp]),
     "selhip_ctx_timing": (_i, [_vp, _i]),
     "selhip_multi_select": (_i, [_vp, _i, _vp, _vp, _vp, _i64, _i, _i, _i, _i, _i, C.c_float, _i, _i, _i, _vp, _i64, C.POINTER(_i64), C.POINTER(_i64)]),
+    "selhip_ooc_select": (_i, [_i, _vp, _vp, _vp, _vp, _i, _i, _i64, _i, _i, _i, _i, _i, C.c_float, _i, _i, _i64, _i,
+                               _vp, _i64, C.POINTER(_i64), C.POINTER(_i64)]),
+    "selhip_ctx_set_candidate_begin": (_i, [_vp, _i64]),
     "selhip_smh_a_pairs": (_i, [_vp, _i, _i, _i, _vp, _i64, _vp, _vp]),
     "selhip_hll_union_hist": (_i, [_vp, _i, _vp, _i64, _vp, _vp]),
     "selhip_ertl_estimate": (_i, [_vp, _i64, _i, _i, _vp, _vp]),

@@ -10,7 +10,9 @@ namespace {
 //   hi[i]    = last k such that CB(tau, e_i, e_k) holds, or N-1 without CB  (criteria_sketch.hpp:45-49;
 //              the loop `break`s at the first failing k (selection.cpp:282-283); e is ascending so the
 //              predicate is monotone and the break is exactly "k <= hi(i)")
-//   z0       = first rank with e != 0  (`if(e2 == 0) continue`, selection.cpp:281)
+//   z0       = first rank with e != 0  (`if(e2 == 0) continue`, selection.cpp:281), raised to cand_begin when the pass is
+//              restricted to candidates k >= cand_begin (rectangular passes of the out-of-core driver): every kernel
+//              takes its first candidate as max(i+1, z0), so this one number carries the restriction
 // It is the first kernel of a pass, so it also clears the per-row counters of the stage-2 grouping (saves a memset).
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ bool cb_pred(double tau, u64 e1, u64 e2) {
@@ -20,7 +22,7 @@ __device__ __forceinline__ bool cb_pred(double tau, u64 e1, u64 e2) {
 
 __global__ void cb_bounds_kernel(const double* __restrict__ cards, int n, double tau, int use_cb,
                                  RowMap rm, u64* __restrict__ ecard, int* __restrict__ hi,
-                                 PassCounters* __restrict__ pc, int* __restrict__ csr_zero) {
+                                 PassCounters* __restrict__ pc, int* __restrict__ csr_zero, int cand_begin) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     if (csr_zero) { csr_zero[i] = 0; csr_zero[n + i] = 0; }     // stage 2's per-row counters (count / fill cursors) for this pass
@@ -30,9 +32,9 @@ __global__ void cb_bounds_kernel(const double* __restrict__ cards, int n, double
     if (i > 0) {
         double cp = cards[i - 1];
         if (c < cp) pc->unsorted = 1;
-        if (e1 != 0 && selhip::trunc_card(cp) == 0) pc->z0p1 = i + 1;
+        if (e1 != 0 && selhip::trunc_card(cp) == 0) pc->z0p1 = max(i, cand_begin) + 1;
     } else if (e1 != 0) {
-        pc->z0p1 = 1;
+        pc->z0p1 = max(0, cand_begin) + 1;
     }
     int h = n - 1;
     if (use_cb) {
@@ -60,6 +62,7 @@ __global__ void cb_bounds_kernel(const double* __restrict__ cards, int n, double
             }
             first = lo;
         }
+        if (first < cand_begin) first = cand_begin;
         long long cnt = (long long)h - first + 1;
         if (cnt > 0) atomicAdd(&pc->n_evaluated, (u64)cnt);
     }

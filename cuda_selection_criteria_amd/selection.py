@@ -161,6 +161,10 @@ class Selector:
         """the following runs evaluate only the row blocks b (of block_rows rows) with b % n_parts == part"""
         check(self._lib.selhip_ctx_set_row_interleave(self._ctx, block_rows, n_parts, part), self._ctx)
 
+    def set_candidate_begin(self, k_min: int):
+        """rectangular passes: the following runs only take candidates k >= k_min (reset by upload/attach)"""
+        check(self._lib.selhip_ctx_set_candidate_begin(self._ctx, k_min), self._ctx)
+
     def set_param(self, name: str, value: int):
         check(self._lib.selhip_ctx_set_param(self._ctx, name.encode(), value), self._ctx)
 
@@ -294,6 +298,35 @@ def multi_select(devices: Sequence[int], hll: np.ndarray, aux: np.ndarray, cards
         st = (C.c_int64 * 4)()
         rc = lib.selhip_multi_select(devs, len(devices), hll.ctypes.data, aux.ctypes.data, cards.ctypes.data, n, m, 14, mode, algo,
                                      fp_mode, np.float32(tau), n_rows, n_bands, gather, out.ctypes.data, cap, C.byref(cnt), st)
+        if rc == -3:
+            cap = int(cnt.value)
+            continue
+        check(rc)
+        return out[:cnt.value], {"evaluated": st[0], "survivors": st[1], "selected": st[2], "candidates": st[3]}
+
+
+def ooc_select(hll: np.ndarray, aux: np.ndarray, cards: np.ndarray, tau: float, block_genomes: int,
+               mode: int = MODE_CB_SMH, n_rows: Optional[int] = None, n_bands: Optional[int] = None, algo: int = ALGO_AUTO,
+               fp_mode: int = FP_FMA, n_streams: int = 2, device: int = 0, criterion: int = 0,
+               aux_hll: Optional[np.ndarray] = None, p_aux: int = 0):
+    """selhip_ooc_select: the sketches stay in host memory, at most n_streams * 2 * block_genomes of them are on the device
+    at a time; same result as one in-core pass.  Returns (pairs with global ranks sorted by (i,k), stats dict)."""
+    lib = hip_lib()
+    hll = np.ascontiguousarray(hll, dtype=np.uint8)
+    aux = np.ascontiguousarray(aux, dtype=np.uint64)
+    cards = np.ascontiguousarray(cards, dtype=np.float64)
+    n, m = aux.shape
+    if n_rows is None or n_bands is None:
+        n_rows, n_bands = banding(m, tau)
+    ah = np.ascontiguousarray(aux_hll, dtype=np.uint8) if aux_hll is not None and criterion != 0 else None
+    cap = 1 << 16
+    while True:
+        out = np.zeros(cap, dtype=PAIR_DTYPE)
+        cnt = C.c_int64()
+        st = (C.c_int64 * 4)()
+        rc = lib.selhip_ooc_select(device, hll.ctypes.data, aux.ctypes.data, cards.ctypes.data,
+                                   ah.ctypes.data if ah is not None else None, p_aux, criterion, n, m, 14, mode, algo, fp_mode,
+                                   np.float32(tau), n_rows, n_bands, block_genomes, n_streams, out.ctypes.data, cap, C.byref(cnt), st)
         if rc == -3:
             cap = int(cnt.value)
             continue

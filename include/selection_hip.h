@@ -120,6 +120,10 @@ int selhip_ctx_set_pipeline(selhip_ctx* ctx, int chunks);
  * Every rank then gets the same share of the pair space AND of the survivors, whatever the triangle's shape (a contiguous
  * equal-pair cut hands the last of 8 ranks ~35 % of all rows, i.e. of all stage-2 work).  n_parts <= 1 switches it off. */
 int selhip_ctx_set_row_interleave(selhip_ctx* ctx, int block_rows, int n_parts, int part);
+/* Rectangular passes: the following runs only take candidates k >= k_min (in addition to k > i), i.e. rows [row_begin,
+ * row_end) x columns [k_min, n).  With the uploaded array = block I followed by block J of a larger sorted set,
+ * rows [0, |I|) and k_min = |I| evaluates exactly the pairs I x J (the out-of-core driver below).  Reset to 0 by upload/attach. */
+int selhip_ctx_set_candidate_begin(selhip_ctx* ctx, int64_t k_min);
 /* Tunables (integers by name; results never depend on them):
  *   "join_qt"     query rows per block of the signature join (multiple of 16, default 128)
  *   "join_bits"   16 (default): all-pairs join on 16-bit band signatures packed two per dword, its matches cut back to the
@@ -221,6 +225,25 @@ int selhip_multi_select(const int* devices, int n_devices,
                         const uint8_t* h_hll, const uint64_t* h_aux, const double* h_cards,
                         int64_t n_genomes, int m, int p_hll, int mode, int algo, int fp_mode, float tau_f, int n_rows, int n_bands,
                         int gather, selhip_pair_t* h_out, int64_t cap, int64_t* count_out, int64_t stats_out[4]);
+
+/* ---------------------------------------------------------------------------------------------------
+ * 2c. Out-of-core driver: the sketches stay in HOST memory (all n genomes, ascending
+ *     cardinality, h_cards required) and only `block_genomes` of them per block are resident on the device at a time.
+ *     The pair space is tiled into block pairs (I, J), I <= J: a diagonal block is an ordinary pass over I; an
+ *     off-diagonal one uploads I followed by J and runs rows I x candidates J (selhip_ctx_set_candidate_begin), so every
+ *     pair is evaluated exactly once and the result -- pairs, Jaccard values, statistics -- is identical to one in-core
+ *     pass over the whole set.  n_streams = 2 runs two block pairs at a time (own buffers, own context, own host thread):
+ *     the upload of one overlaps the pass of the other; device memory needed ~ n_streams * 2 * block_genomes sketches.
+ *     h_aux_hll/p_aux are only needed for criteria other than SELHIP_CRIT_SMH_A (NULL/0 otherwise).
+ *     h_out receives min(count, cap) records with GLOBAL ranks, sorted by (i,k); SELHIP_E_OVERFLOW (count still exact)
+ *     if cap was too small.
+ * --------------------------------------------------------------------------------------------------- */
+int selhip_ooc_select(int device, const uint8_t* h_hll, const uint64_t* h_aux, const double* h_cards,
+                      const uint8_t* h_aux_hll, int p_aux, int criterion,
+                      int64_t n, int m, int p_hll, int mode, int algo, int fp_mode, float tau_f, int n_rows, int n_bands,
+                      int64_t block_genomes, int n_streams,
+                      selhip_pair_t* h_out, int64_t cap, int64_t* count_out, int64_t stats_out[4]);
+
 
 /* ---------------------------------------------------------------------------------------------------
  * 3. Building blocks (device pointers), used by the launchers above and exposed for tests.

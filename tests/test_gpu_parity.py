@@ -539,6 +539,56 @@ def test_unsorted_cards_rejected(oracle):
             sel.upload(hll, aux, cards[::-1].copy())
 
 
+def test_rectangular_pass_and_out_of_core_driver(oracle):
+    """(1) a pass restricted to candidates k >= k_min evaluates exactly rows x [k_min, n); (2) the
+    out-of-core driver -- sketches in host memory, block pairs (I, J) uploaded in turn -- returns the in-core result
+    (pairs, Jaccard bits, evaluated / survivor counts) for every block size, CB on and off, every algorithm, one and two
+    streams, a set with empty sketches, and the auxiliary-HLL criteria"""
+    cfg = make_golden.GOLDEN_SYNTH["synth_spread_n600_m64"]
+    hll, aux, cards, _, aux_hll = sorted_set(cfg, oracle)
+    tau = 0.5
+    r, b = pkg.banding(cfg.m, tau)
+    n = len(cards)
+    for use_cb, mode in ((True, MODE_CB_SMH), (False, MODE_SMH)):
+        want, st = oracle.select(hll, aux, cards, tau, r, b, use_cb=use_cb)
+        assert len(want) > 50
+        with Selector(0) as sel:
+            sel.upload(hll, aux, cards)
+            for algo in (ALGO_AUTO, ALGO_STREAM, ALGO_HASHJOIN):
+                for k_min, rows in ((0, (0, n)), (200, (0, 200)), (333, (100, 333)), (n, (0, n)), (64, (0, 500))):
+                    sel.set_candidate_begin(k_min)
+                    got = sel.run(tau, mode, r, b, rows=rows, algo=algo)
+                    ref = want[(want["i"] >= rows[0]) & (want["i"] < rows[1]) & (want["k"] >= k_min)]
+                    assert_same_pairs(got, ref)
+            with pytest.raises(pkg.SelhipError):
+                sel.set_candidate_begin(n + 1)
+            sel.upload(hll, aux, cards)                      # a new upload resets the restriction
+            assert_same_pairs(sel.run(tau, mode, r, b), want)
+        for block, streams, algo in ((128, 2, ALGO_AUTO), (100, 1, ALGO_AUTO), (599, 2, ALGO_STREAM), (600, 1, ALGO_AUTO), (5000, 2, ALGO_AUTO),
+                                     (64, 3, ALGO_HASHJOIN), (250, 2, ALGO_SIG)):
+            got, s = pkg.ooc_select(hll, aux, cards, tau, block, mode, r, b, algo=algo, n_streams=streams)
+            assert_same_pairs(got, want)
+            assert s["evaluated"] == st["evaluated"] and s["survivors"] == st["survivors"], (block, streams, s, st)
+    # empty sketches at the front (cardinality 0: skipped as candidates, selection.cpp:281) across block boundaries
+    hll0, aux0 = hll.copy(), aux.copy()
+    hll0[:150] = 0
+    cards0 = oracle.cards(hll0)
+    assert (cards0[:150] == 0).all() and (np.diff(cards0) >= 0).all()
+    want0, st0 = oracle.select(hll0, aux0, cards0, tau, r, b)
+    got0, s0 = pkg.ooc_select(hll0, aux0, cards0, tau, 100, MODE_CB_SMH, r, b)
+    assert_same_pairs(got0, want0)
+    assert s0["evaluated"] == st0["evaluated"]
+    # auxiliary-HLL criteria through the driver
+    for crit, code in (("hll_a", pkg.CRIT_HLL_A), ("hll_an", pkg.CRIT_HLL_AN), ("two-stage", pkg.CRIT_HLL_A_SMH_A)):
+        wantc, _ = oracle.select(hll, aux, cards, tau, r, b, criterion={"hll_a": 1, "hll_an": 2, "two-stage": 3}[crit], aux_hll=aux_hll, p_aux=cfg.p_aux)
+        gotc, _ = pkg.ooc_select(hll, aux, cards, tau, 170, MODE_CB_SMH, r, b, criterion=code, aux_hll=aux_hll, p_aux=cfg.p_aux)
+        assert_same_pairs(gotc, wantc)
+    with pytest.raises(pkg.SelhipError):
+        pkg.ooc_select(hll, aux, cards[::-1].copy(), tau, 100, MODE_CB_SMH, r, b)          # not sorted
+    with pytest.raises(pkg.SelhipError):
+        pkg.ooc_select(hll, aux, cards, tau, 0, MODE_CB_SMH, r, b)                          # bad block size
+
+
 def test_multi_device_entry_and_rccl_gather(oracle):
     """selhip_multi_select (device list, one process): RCCL all_gather with one rank, host merge with several
     contexts sharing the one card, RCCL-or-host fallback when RCCL refuses duplicate devices"""
