@@ -124,6 +124,15 @@ HOST_SYMBOLS = {
     "selhost_dataset_cards": (_vp, [_vp]),
     "selhost_dataset_name": (_cp, [_vp, _i64]),
     "selhost_format_line": (_i, [_cp, _cp, _d, _vp, _sz]),
+    "selhost_write_results": (_i, [C.c_char_p, _vp, _i64, _vp, _i64, C.c_float]),
+    "selhost_read_results": (_i, [_vp, C.c_char_p]),
+    "selhost_results_free": (None, [_vp]),
+    "selhost_results_count": (_i64, [_vp]),
+    "selhost_results_names": (_i64, [_vp]),
+    "selhost_results_tau": (C.c_float, [_vp]),
+    "selhost_results_pairs": (_vp, [_vp]),
+    "selhost_results_name": (C.c_char_p, [_vp, _i64]),
+    "selhost_results_text": (_i64, [_vp, _vp, C.c_size_t]),
     "selhost_synth_generate": (_i, [C.POINTER(Synth), _i64, _i64, _vp, _vp, _vp, _i]),
     "selhost_shard_rows": (_i, [_i64, _vp, _i64, _i, _vp]),
     "selhost_version": (_cp, []),

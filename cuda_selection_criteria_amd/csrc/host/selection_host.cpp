@@ -296,6 +296,103 @@ int selhost_format_line(const char* fn1, const char* fn2, double jaccard, char* 
     return (w < 0 || (size_t)w >= cap) ? SELHOST_E_BADARG : w;
 }
 
+// ---- on-disk result format ---------------------------------------------------------------------------------
+struct selhost_results {
+    std::vector<selhost_pair_t> pairs;
+    std::vector<std::string> names;
+    float tau = 0.f;
+};
+
+namespace {
+struct ResultHeader { char magic[4]; uint32_t version; uint64_t n_pairs, n_names, names_bytes; float tau; uint32_t reserved; };
+static_assert(sizeof(ResultHeader) == 40, "result header layout");
+static_assert(sizeof(selhost_pair_t) == 16, "result record layout");
+}  // namespace
+
+int selhost_write_results(const char* path, const selhost_pair_t* pairs, int64_t n_pairs,
+                          const char* const* names, int64_t n_names, float tau) {
+    if (!path || n_pairs < 0 || n_names < 0 || (n_pairs && !pairs) || (n_names && !names)) return fail(SELHOST_E_BADARG, "bad argument");
+    for (int64_t j = 0; j < n_pairs; ++j)
+        if (pairs[j].i < 0 || pairs[j].k < 0 || (n_names && (pairs[j].i >= n_names || pairs[j].k >= n_names)))
+            return fail(SELHOST_E_BADARG, "record %lld refers to a rank outside the name table", (long long)j);
+    std::string blob;
+    for (int64_t g = 0; g < n_names; ++g) {
+        if (!names[g]) return fail(SELHOST_E_BADARG, "null name");
+        blob.append(names[g]);
+        blob.push_back('\0');
+    }
+    ResultHeader h;
+    std::memcpy(h.magic, "SELR", 4);
+    h.version = 1; h.n_pairs = (uint64_t)n_pairs; h.n_names = (uint64_t)n_names; h.names_bytes = blob.size(); h.tau = tau; h.reserved = 0;
+    FILE* fp = std::fopen(path, "wb");
+    if (!fp) return fail(SELHOST_E_IO, "cannot open %s for writing", path);
+    bool ok = std::fwrite(&h, sizeof h, 1, fp) == 1;
+    ok = ok && (blob.empty() || std::fwrite(blob.data(), 1, blob.size(), fp) == blob.size());
+    ok = ok && (n_pairs == 0 || std::fwrite(pairs, sizeof(selhost_pair_t), (size_t)n_pairs, fp) == (size_t)n_pairs);
+    ok = (std::fclose(fp) == 0) && ok;
+    return ok ? SELHOST_OK : fail(SELHOST_E_IO, "short write to %s", path);
+}
+
+int selhost_read_results(selhost_results** out, const char* path) {
+    if (!out || !path) return fail(SELHOST_E_BADARG, "bad argument");
+    *out = nullptr;
+    FILE* fp = std::fopen(path, "rb");
+    if (!fp) return fail(SELHOST_E_IO, "cannot open %s", path);
+    std::unique_ptr<FILE, int (*)(FILE*)> guard(fp, std::fclose);
+    ResultHeader h;
+    if (std::fread(&h, sizeof h, 1, fp) != 1) return fail(SELHOST_E_IO, "short read (header) from %s", path);
+    if (std::memcmp(h.magic, "SELR", 4) || h.version != 1) return fail(SELHOST_E_FORMAT, "%s is not a version-1 result file", path);
+    if (h.n_pairs > (1ull << 40) || h.n_names > (1ull << 32) || h.names_bytes > (1ull << 40) || h.names_bytes < h.n_names)
+        return fail(SELHOST_E_FORMAT, "implausible sizes in %s", path);
+    std::unique_ptr<selhost_results> r(new selhost_results);
+    r->tau = h.tau;
+    std::string blob((size_t)h.names_bytes, '\0');
+    if (h.names_bytes && std::fread(&blob[0], 1, blob.size(), fp) != blob.size()) return fail(SELHOST_E_IO, "short read (names) from %s", path);
+    size_t pos = 0;
+    for (uint64_t g = 0; g < h.n_names; ++g) {
+        const void* z = pos < blob.size() ? std::memchr(blob.data() + pos, 0, blob.size() - pos) : nullptr;
+        if (!z) return fail(SELHOST_E_FORMAT, "name table of %s is truncated", path);
+        const size_t len = (size_t)((const char*)z - (blob.data() + pos));
+        r->names.emplace_back(blob.data() + pos, len);
+        pos += len + 1;
+    }
+    r->pairs.resize((size_t)h.n_pairs);
+    if (h.n_pairs && std::fread(r->pairs.data(), sizeof(selhost_pair_t), (size_t)h.n_pairs, fp) != (size_t)h.n_pairs)
+        return fail(SELHOST_E_IO, "short read (records) from %s", path);
+    for (const selhost_pair_t& pr : r->pairs)
+        if (pr.i < 0 || pr.k < 0 || (h.n_names && ((uint64_t)pr.i >= h.n_names || (uint64_t)pr.k >= h.n_names)))
+            return fail(SELHOST_E_FORMAT, "a record of %s refers to a rank outside the name table", path);
+    *out = r.release();
+    return SELHOST_OK;
+}
+
+void selhost_results_free(selhost_results* r) { delete r; }
+int64_t selhost_results_count(const selhost_results* r) { return r ? (int64_t)r->pairs.size() : SELHOST_E_BADARG; }
+int64_t selhost_results_names(const selhost_results* r) { return r ? (int64_t)r->names.size() : SELHOST_E_BADARG; }
+float selhost_results_tau(const selhost_results* r) { return r ? r->tau : 0.f; }
+const selhost_pair_t* selhost_results_pairs(const selhost_results* r) { return r && !r->pairs.empty() ? r->pairs.data() : nullptr; }
+const char* selhost_results_name(const selhost_results* r, int64_t rank) {
+    if (!r || rank < 0 || rank >= (int64_t)r->names.size()) return nullptr;
+    return r->names[(size_t)rank].c_str();
+}
+int64_t selhost_results_text(const selhost_results* r, char* buf, size_t cap) {
+    if (!r) return SELHOST_E_BADARG;
+    if (r->names.empty() && !r->pairs.empty()) return fail(SELHOST_E_FORMAT, "the file carries no name table");
+    std::string out;
+    char line[8192];
+    for (const selhost_pair_t& pr : r->pairs) {
+        const int w = selhost_format_line(r->names[(size_t)pr.i].c_str(), r->names[(size_t)pr.k].c_str(), pr.jaccard, line, sizeof line);
+        if (w < 0) return fail(SELHOST_E_BADARG, "line too long");
+        out.append(line, (size_t)w);
+    }
+    if (buf && cap) {
+        const size_t c = std::min(cap - 1, out.size());
+        std::memcpy(buf, out.data(), c);
+        buf[c] = '\0';
+    }
+    return (int64_t)out.size();
+}
+
 // ---- synthetic sketches -------------------------------------------------------------------------------
 int selhost_synth_generate(const selhost_synth_t* in, int64_t g_begin, int64_t g_end,
                            uint8_t* hll, uint64_t* aux, uint8_t* aux_hll, int n_threads) {

@@ -14,6 +14,11 @@
 //   -n          no CB pruning ("smh_a" mode of experiments/src/time_smh.cpp:229-257)
 //   -A <algo>   stage-1 algorithm: auto | stream | sig
 //   -F <0|1>    estimator flavour: 1 = FMA (reference Makefile build on FMA hosts, default), 0 = strict
+//   -B <n>      out-of-core: keep the sketches in host memory and process the pair space in blocks of n genomes
+//               (selhip_ooc_select; same output); 0 = everything resident on the device (default)
+//   -o <file>   write the result as a binary result file (include/selection_host.h: "SELR" format: records + name table)
+//               instead of text on stdout
+//   -r <file>   no selection: print the text form of a result file written with -o (needs no GPU)
 //   -x          usage
 #include <unistd.h>
 
@@ -33,10 +38,15 @@ int main(int argc, char* argv[]) {
     int aux_bytes = 256;                 // selection_cuda.cpp:63
     std::string criterion = "smh_a";
     int threads = 8, n_gpus = 1, mode = SELHIP_MODE_CB_SMH, algo = SELHIP_ALGO_AUTO, fp_mode = SELHIP_FP_FMA;
+    long long ooc_block = 0;
+    std::string out_file = "", dump_file = "";
     int c;
-    while ((c = getopt(argc, argv, "xl:b:a:h:c:t:g:nA:F:")) != -1) {
+    while ((c = getopt(argc, argv, "xl:b:a:h:c:t:g:nA:F:B:o:r:")) != -1) {
         switch (c) {
-            case 'x': std::cout << "Usage: -l -h -a -b [-c smh_a] [-t threads] [-g gpus] [-n] [-A auto|stream|sig] [-F 0|1]\n"; return 0;
+            case 'x': std::cout << "Usage: -l -h -a -b [-c smh_a] [-t threads] [-g gpus] [-n] [-A auto|stream|sig] [-F 0|1] [-B block] [-o file] | -r file\n"; return 0;
+            case 'B': ooc_block = std::stoll(optarg); break;
+            case 'o': out_file = optarg; break;
+            case 'r': dump_file = optarg; break;
             case 'l': list_file = optarg; break;
             case 'b': break;
             case 'a': aux_bytes = std::stoi(optarg); break;
@@ -49,6 +59,18 @@ int main(int argc, char* argv[]) {
             case 'F': fp_mode = std::stoi(optarg) ? SELHIP_FP_FMA : SELHIP_FP_STRICT; break;
             default: break;
         }
+    }
+    if (!dump_file.empty()) {
+        selhost_results* res = nullptr;
+        if (selhost_read_results(&res, dump_file.c_str())) { std::cerr << "selection: " << selhost_last_error() << "\n"; return 5; }
+        const int64_t need = selhost_results_text(res, nullptr, 0);
+        if (need < 0) { std::cerr << "selection: " << selhost_last_error() << "\n"; selhost_results_free(res); return 5; }
+        std::string text((size_t)need + 1, '\0');
+        selhost_results_text(res, &text[0], text.size());
+        text.resize((size_t)need);
+        std::cout << text;
+        selhost_results_free(res);
+        return 0;
     }
     int crit = SELHIP_CRIT_SMH_A;
     if (criterion == "hll_a") crit = SELHIP_CRIT_HLL_A;
@@ -79,7 +101,21 @@ int main(int argc, char* argv[]) {
     if (n_gpus > avail) n_gpus = avail;
 
     std::vector<std::vector<selhip_pair_t>> parts(1);
-    if (n_gpus > 1 && crit == SELHIP_CRIT_SMH_A) {
+    if (ooc_block > 0) {
+        // sketches stay in host memory; block pairs are uploaded in turn (two at a time: upload overlaps compute)
+        int64_t cnt = 0, cap = 1 << 20;
+        for (int attempt = 0; attempt < 2; ++attempt) {
+            parts[0].resize((size_t)cap);
+            int r = selhip_ooc_select(0, selhost_dataset_hll(ds), aux_ptr, selhost_dataset_cards(ds),
+                                      p_aux ? selhost_dataset_aux_hll(ds) : nullptr, (int)p_aux, crit, n, m_up, 14,
+                                      mode, algo, fp_mode, threshold, n_rows, n_bands, ooc_block, 2, parts[0].data(), cap, &cnt, nullptr);
+            if (r == SELHIP_E_OVERFLOW && attempt == 0) { cap = cnt; continue; }
+            if (r) { std::cerr << "selection: " << selhip_last_error(nullptr) << "\n"; return 4; }
+            break;
+        }
+        parts[0].resize((size_t)cnt);
+        n_gpus = 1;
+    } else if (n_gpus > 1 && crit == SELHIP_CRIT_SMH_A) {
         // one process, one thread + context per device, selected pairs gathered over RCCL/xGMI (host merge if RCCL is
         // unavailable): selhip_multi_select
         std::vector<int> devs((size_t)n_gpus);
@@ -115,6 +151,16 @@ int main(int argc, char* argv[]) {
         selhip_ctx_destroy(ctx);
     }
 
+    if (!out_file.empty()) {
+        std::vector<const char*> names((size_t)n);
+        for (int64_t g = 0; g < n; ++g) names[(size_t)g] = selhost_dataset_name(ds, g);
+        static_assert(sizeof(selhost_pair_t) == sizeof(selhip_pair_t), "record layouts must agree");
+        const int r = selhost_write_results(out_file.c_str(), reinterpret_cast<const selhost_pair_t*>(parts[0].data()), (int64_t)parts[0].size(),
+                                            names.data(), n, threshold);
+        if (r) { std::cerr << "selection: " << selhost_last_error() << "\n"; return 5; }
+        selhost_dataset_free(ds);
+        return 0;
+    }
     // shards are contiguous row ranges and each part is sorted by (i,k): concatenation = print order
     std::string out;
     char line[8192];

@@ -83,6 +83,43 @@ def format_lines(names: Sequence[str], pairs: np.ndarray) -> str:
     return "".join(out)
 
 
+def write_results(path: str, pairs: np.ndarray, names: Sequence[str], tau: float = 0.0):
+    """binary result file of include/selection_host.h (records + the name table their ranks refer to)"""
+    h = host_lib()
+    rec = np.ascontiguousarray(pairs, dtype=PAIR_DTYPE)
+    enc = [n.encode() for n in names]
+    arr = (C.c_char_p * len(enc))(*enc)
+    rc = h.selhost_write_results(str(path).encode(), rec.ctypes.data if len(rec) else None, len(rec), arr if enc else None, len(enc),
+                                 np.float32(tau))
+    if rc:
+        raise RuntimeError(h.selhost_last_error().decode())
+
+
+def read_results(path: str):
+    """-> (pairs[PAIR_DTYPE], names, tau, text) of a result file; text = the reference's stdout form"""
+    h = host_lib()
+    r = C.c_void_p()
+    rc = h.selhost_read_results(C.byref(r), str(path).encode())
+    if rc:
+        raise RuntimeError(h.selhost_last_error().decode())
+    try:
+        cnt = h.selhost_results_count(r)
+        nn = h.selhost_results_names(r)
+        pairs = np.zeros(cnt, dtype=PAIR_DTYPE)
+        if cnt:
+            C.memmove(pairs.ctypes.data, h.selhost_results_pairs(r), cnt * PAIR_DTYPE.itemsize)
+        names = [h.selhost_results_name(r, g).decode() for g in range(nn)]
+        need = h.selhost_results_text(r, None, 0)
+        text = ""
+        if need > 0:
+            buf = C.create_string_buffer(need + 1)
+            h.selhost_results_text(r, buf, need + 1)
+            text = buf.raw[:need].decode()
+        return pairs, names, float(h.selhost_results_tau(r)), text
+    finally:
+        h.selhost_results_free(r)
+
+
 class Selector:
     """One selhip context = one GPU (`selhip_ctx_*`, include/selection_hip.h section 2)."""
 

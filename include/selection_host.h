@@ -78,6 +78,27 @@ const char*     selhost_dataset_name(const selhost_dataset* ds, int64_t rank);
 /* "fn1 fn2 0.946107\n" (std::to_string(double) == "%f"); returns bytes written (excluding NUL) or <0 */
 int selhost_format_line(const char* fn1, const char* fn2, double jaccard, char* buf, size_t cap);
 
+/* ---- on-disk result format (the reference only prints text, selection.cpp:297-300) ---------
+ * A self-contained binary file: the selected pairs as 16-byte records plus the table of genome names their ranks refer to.
+ *   header (40 B, little endian): char magic[4] = "SELR"; u32 version = 1; u64 n_pairs; u64 n_names; u64 names_bytes;
+ *                                 f32 tau; u32 reserved = 0
+ *   names   : n_names NUL-terminated strings, rank order (names_bytes bytes in total)
+ *   records : n_pairs x { i32 i; i32 k; f64 jaccard }  (selhost_pair_t == selhip_pair_t), sorted by (i, k)
+ * selhost_results_text(file) reproduces the reference's stdout lines "fn1 fn2 <to_string(J)>" byte for byte. */
+typedef struct { int32_t i, k; double jaccard; } selhost_pair_t;
+int selhost_write_results(const char* path, const selhost_pair_t* pairs, int64_t n_pairs,
+                          const char* const* names, int64_t n_names, float tau);
+typedef struct selhost_results selhost_results;
+int selhost_read_results(selhost_results** out, const char* path);
+void selhost_results_free(selhost_results* r);
+int64_t selhost_results_count(const selhost_results* r);
+int64_t selhost_results_names(const selhost_results* r);
+float selhost_results_tau(const selhost_results* r);
+const selhost_pair_t* selhost_results_pairs(const selhost_results* r);
+const char* selhost_results_name(const selhost_results* r, int64_t rank);
+/* text of the whole file into buf (NUL-terminated if it fits); returns the number of bytes needed (excluding NUL) or <0 */
+int64_t selhost_results_text(const selhost_results* r, char* buf, size_t cap);
+
 /* ---- synthetic sketches on the host (bit-identical to selhip_synth_generate) ------------------- */
 typedef struct {
     uint64_t seed;

@@ -57,3 +57,24 @@ def test_time_smh_hip_records():
     out = subprocess.run([str(BIN / "time_smh_hip"), "-N", "2000", "-h", "0.9", "-m", "256"], capture_output=True, text=True)
     assert out.returncode == 0, out.stderr
     assert "synthetic_N2000;smh_a;0.9;" in out.stdout and "pairs:1999000;" in out.stdout
+
+
+@pytest.mark.gpu
+def test_selection_cli_out_of_core_and_result_file(tmp_path):
+    """-B (sketches in host memory, block pairs uploaded in turn) prints the same lines; -o writes the binary result file
+    and -r turns it back into those lines"""
+    want = (EXP / "influenza_smh_a_a512_h0.01.fma.txt").read_text()
+    for block in ("3", "4", "10", "1000"):
+        out = subprocess.run([str(BIN / "selection"), "-l", "influenza_filelist.txt", "-h", "0.01", "-a", "512", "-B", block],
+                             cwd=GOLDEN, capture_output=True, text=True)
+        assert out.returncode == 0, out.stderr
+        assert out.stdout == want
+    out = subprocess.run([str(BIN / "selection"), "-l", "influenza_filelist.txt", "-h", "0.01", "-a", "256", "-c", "hll_a", "-B", "4"],
+                         cwd=GOLDEN, capture_output=True, text=True)
+    assert out.returncode == 0 and out.stdout == (EXP / "influenza_hll_a_a256_h0.01.fma.txt").read_text()
+    f = tmp_path / "sel.selr"
+    out = subprocess.run([str(BIN / "selection"), "-l", "influenza_filelist.txt", "-h", "0.01", "-a", "512", "-o", str(f)],
+                         cwd=GOLDEN, capture_output=True, text=True)
+    assert out.returncode == 0 and out.stdout == "", out.stderr
+    out = subprocess.run([str(BIN / "selection"), "-r", str(f)], capture_output=True, text=True)
+    assert out.returncode == 0 and out.stdout == want

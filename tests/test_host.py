@@ -179,6 +179,46 @@ def test_format_line(host):
     assert host.selhost_format_line(b"a", b"b", 1.0, buf, 3) < 0
 
 
+def test_result_file_roundtrip_and_errors(tmp_path, host):
+    """binary result file (records + name table): round trip, text form == format_lines, the CLI dumps it without a GPU,
+    malformed files are refused"""
+    import subprocess
+    names = ["influenza/a.fna.gz", "influenza/b.fna.gz", "c", "d with space"]
+    pairs = np.zeros(3, dtype=pkg.PAIR_DTYPE)
+    pairs["i"] = [0, 0, 2]; pairs["k"] = [1, 3, 3]; pairs["jaccard"] = [0.94610712345, 1.0, 0.5]
+    f = tmp_path / "sel.selr"
+    pkg.write_results(f, pairs, names, tau=0.9)
+    assert f.stat().st_size == 40 + sum(len(n) + 1 for n in names) + 3 * 16
+    got, gnames, tau, text = pkg.read_results(f)
+    assert gnames == names and tau == np.float32(0.9)
+    assert np.array_equal(got["i"], pairs["i"]) and np.array_equal(got["k"], pairs["k"])
+    assert np.array_equal(got["jaccard"].view(np.uint64), pairs["jaccard"].view(np.uint64))
+    assert text == pkg.format_lines(names, pairs) and text.startswith("influenza/a.fna.gz influenza/b.fna.gz 0.946107\n")
+    out = subprocess.run([str(ROOT / "cuda_selection_criteria_amd" / "bin" / "selection"), "-r", str(f)], capture_output=True, text=True)
+    assert out.returncode == 0 and out.stdout == text
+    # empty result
+    pkg.write_results(tmp_path / "empty.selr", pairs[:0], names)
+    e, en, _, et = pkg.read_results(tmp_path / "empty.selr")
+    assert len(e) == 0 and en == names and et == ""
+    # a rank outside the name table is refused on both sides
+    bad = pairs.copy(); bad["k"][2] = 4
+    with pytest.raises(RuntimeError):
+        pkg.write_results(tmp_path / "bad.selr", bad, names)
+    raw = bytearray(f.read_bytes())
+    raw[-16 + 4] = 9                                    # k of the last record -> 9
+    (tmp_path / "bad2.selr").write_bytes(raw)
+    with pytest.raises(RuntimeError):
+        pkg.read_results(tmp_path / "bad2.selr")
+    (tmp_path / "trunc.selr").write_bytes(f.read_bytes()[:-5])
+    with pytest.raises(RuntimeError):
+        pkg.read_results(tmp_path / "trunc.selr")
+    (tmp_path / "magic.selr").write_bytes(b"NOPE" + f.read_bytes()[4:])
+    with pytest.raises(RuntimeError):
+        pkg.read_results(tmp_path / "magic.selr")
+    with pytest.raises(RuntimeError):
+        pkg.read_results(tmp_path / "missing.selr")
+
+
 def test_synth_host_deterministic_and_statistics(oracle):
     cfg = SynthConfig("t", 40, 256, 0.9, 123, p_aux=8, n_sh_lo=20000, n_sh_hi=20000)
     a1 = pkg.synth_host(cfg)
