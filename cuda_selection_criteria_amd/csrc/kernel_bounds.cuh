@@ -20,10 +20,9 @@ __device__ __forceinline__ bool cb_pred(double tau, u64 e1, u64 e2) {
     return gamma >= tau;
 }
 
-__global__ void cb_bounds_kernel(const double* __restrict__ cards, int n, double tau, int use_cb,
-                                 RowMap rm, u64* __restrict__ ecard, int* __restrict__ hi,
-                                 PassCounters* __restrict__ pc, int* __restrict__ csr_zero, int cand_begin) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void cb_bounds_body(int i, const double* __restrict__ cards, int n, double tau, int use_cb,
+                                               RowMap rm, u64* __restrict__ ecard, int* __restrict__ hi,
+                                               PassCounters* __restrict__ pc, int* __restrict__ csr_zero, int cand_begin) {
     if (i >= n) return;
     if (csr_zero) { csr_zero[i] = 0; csr_zero[n + i] = 0; }     // stage 2's per-row counters (count / fill cursors) for this pass
     double c = cards[i];
@@ -66,6 +65,12 @@ __global__ void cb_bounds_kernel(const double* __restrict__ cards, int n, double
         long long cnt = (long long)h - first + 1;
         if (cnt > 0) atomicAdd(&pc->n_evaluated, (u64)cnt);
     }
+}
+
+__global__ void cb_bounds_kernel(const double* __restrict__ cards, int n, double tau, int use_cb,
+                                 RowMap rm, u64* __restrict__ ecard, int* __restrict__ hi,
+                                 PassCounters* __restrict__ pc, int* __restrict__ csr_zero, int cand_begin) {
+    cb_bounds_body((int)(blockIdx.x * blockDim.x + threadIdx.x), cards, n, tau, use_cb, rm, ecard, hi, pc, csr_zero, cand_begin);
 }
 
 }  // namespace

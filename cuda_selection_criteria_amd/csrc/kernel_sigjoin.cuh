@@ -24,12 +24,11 @@ __device__ __forceinline__ u64 mix64(u64 x) {
 // mixes with xor-shuffles (r <= 64) -- or one thread walks the band (r > 64).  Writes both layouts:
 //   sigQ[g][NB] (genome-major), sigT[b][n_pad] (band-major, lane = candidate) and sigP[b/2][n_pad]: the top 16 bits of
 //   the signatures of bands 2d (low half) and 2d+1 (high half) packed in one dword, for the 16-bit join.
-__global__ __launch_bounds__(kBlock)
-void sig_build_kernel(const u64* __restrict__ aux, int n, int m, int r, int nb, int n_pad,
-                      uint32_t* __restrict__ sigQ, uint32_t* __restrict__ sigT, uint32_t* __restrict__ sigP) {
+__device__ __forceinline__ void sig_build_body(long long block, const u64* __restrict__ aux, int n, int m, int r, int nb, int n_pad,
+                                               uint32_t* __restrict__ sigQ, uint32_t* __restrict__ sigT, uint32_t* __restrict__ sigP) {
     uint16_t* const sigP16 = reinterpret_cast<uint16_t*>(sigP);
     if (r <= kWave) {
-        const long long t = (long long)blockIdx.x * kBlock + threadIdx.x;      // global bucket index
+        const long long t = block * kBlock + threadIdx.x;                      // global bucket index
         const long long total = (long long)n * m;
         u64 h = 0;
         int j = 0;
@@ -49,7 +48,7 @@ void sig_build_kernel(const u64* __restrict__ aux, int n, int m, int r, int nb, 
             sigP16[((long long)(b >> 1) * n_pad + g) * 2 + (b & 1)] = (uint16_t)(sig >> 16);
         }
     } else {
-        const long long t = (long long)blockIdx.x * kBlock + threadIdx.x;      // (genome, band)
+        const long long t = block * kBlock + threadIdx.x;                      // (genome, band)
         if (t >= (long long)n * nb) return;
         const int g = (int)(t / nb), b = (int)(t % nb);
         const u64* v = aux + (long long)g * m + (long long)b * r;
@@ -60,6 +59,20 @@ void sig_build_kernel(const u64* __restrict__ aux, int n, int m, int r, int nb, 
         sigT[(long long)b * n_pad + g] = sig;
         sigP16[((long long)(b >> 1) * n_pad + g) * 2 + (b & 1)] = (uint16_t)(sig >> 16);
     }
+}
+
+// One launch for the two kernels every signature pass starts with: the first `bounds_blocks` blocks run cb_bounds_body (a few
+// waves of binary searches, latency-bound), the others build the signatures -- the bounds then cost nothing on the stream.
+__global__ __launch_bounds__(kBlock)
+void sig_build_kernel(const u64* __restrict__ aux, int n, int m, int r, int nb, int n_pad,
+                      uint32_t* __restrict__ sigQ, uint32_t* __restrict__ sigT, uint32_t* __restrict__ sigP,
+                      int bounds_blocks, const double* __restrict__ cards, double tau, int use_cb, RowMap rm,
+                      u64* __restrict__ ecard, int* __restrict__ hi, PassCounters* __restrict__ pc, int* __restrict__ csr_zero, int cand_begin) {
+    if ((int)blockIdx.x < bounds_blocks) {
+        cb_bounds_body((int)(blockIdx.x * kBlock + threadIdx.x), cards, n, tau, use_cb, rm, ecard, hi, pc, csr_zero, cand_begin);
+        return;
+    }
+    sig_build_body((long long)blockIdx.x - bounds_blocks, aux, n, m, r, nb, n_pad, sigQ, sigT, sigP);
 }
 
 // sig_join_kernel<NB>: all-pairs "some band signature equal", entirely on the vector unit.

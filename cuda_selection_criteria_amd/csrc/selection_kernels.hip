@@ -351,13 +351,17 @@ hipError_t launch_join16(selhip_ctx* c, const StageIO& io, int n_pad, int rb, in
     return hipGetLastError();
 }
 
-hipError_t launch_sig_build(selhip_ctx* c, int n_rows, int n_bands) {
+// sig_build with the pass's bounds computation riding in its first blocks (with_bounds) or alone
+hipError_t launch_sig_build(selhip_ctx* c, int n_rows, int n_bands, bool with_bounds, double tau, int rb, int re) {
     const int n = (int)c->n;
     const int n_pad = ((n + kWave - 1) / kWave) * kWave;
     TimerScope t(c, T_SIGBUILD);
     const long long threads = n_rows <= kWave ? (long long)n * c->m : (long long)n * n_bands;
-    hipLaunchKernelGGL(sig_build_kernel, dim3((unsigned)((threads + kBlock - 1) / kBlock)), dim3(kBlock), 0, c->stream,
-                       c->d_aux, n, c->m, n_rows, n_bands, n_pad, c->sigQ.p, c->sigT.p, c->sigP.p);
+    const int bounds_blocks = with_bounds ? (n + kBlock - 1) / kBlock : 0;
+    hipLaunchKernelGGL(sig_build_kernel, dim3((unsigned)((threads + kBlock - 1) / kBlock) + (unsigned)bounds_blocks), dim3(kBlock), 0, c->stream,
+                       c->d_aux, n, c->m, n_rows, n_bands, n_pad, c->sigQ.p, c->sigT.p, c->sigP.p,
+                       bounds_blocks, c->d_cards, tau, c->mode == SELHIP_MODE_CB_SMH ? 1 : 0, row_map(c, rb, re), c->ecard.p, c->hi.p, c->pc.p,
+                       (c->p == 14 && c->group_stage2) ? c->csr_cnt.p : nullptr, (int)c->cand_begin);
     return hipGetLastError();
 }
 
@@ -550,13 +554,6 @@ int enqueue_pass(selhip_ctx* c) {
     }
     TimerScope total(c, T_TOTAL);
     HIPCHK(&c->err, hipMemsetAsync(c->pc.p, 0, sizeof(PassCounters) * (kMaxChunks + 1), c->stream));
-    {
-        TimerScope t(c, T_PREP);
-        hipLaunchKernelGGL(cb_bounds_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream,
-                           c->d_cards, n, tau, c->mode == SELHIP_MODE_CB_SMH ? 1 : 0, row_map(c, rb, re), c->ecard.p, c->hi.p, pc0,
-                           (c->p == 14 && c->group_stage2) ? c->csr_cnt.p : nullptr, (int)c->cand_begin);
-        HIPCHK(&c->err, hipGetLastError());
-    }
     const bool smh_crit = crit == SELHIP_CRIT_SMH_A || crit == SELHIP_CRIT_HLL_A_SMH_A;
     const bool use_hash = smh_crit && c->algo == SELHIP_ALGO_HASHJOIN;
     const bool use_sig = use_hash || (smh_crit && (c->algo == SELHIP_ALGO_SIG || c->algo == SELHIP_ALGO_AUTO) &&
@@ -569,7 +566,16 @@ int enqueue_pass(selhip_ctx* c) {
         set_err(&c->err, "ALGO_HASHJOIN needs power-of-two rows (got %d x %d)", c->n_rows, c->n_bands);
         return SELHIP_E_BADARG;
     }
-    if (use_sig) HIPCHK(&c->err, launch_sig_build(c, c->n_rows, c->n_bands));
+    if (use_sig) {
+        // bounds (truncated cards, CB cut-offs, z0, evaluated count) ride in the first blocks of the signature build
+        HIPCHK(&c->err, launch_sig_build(c, c->n_rows, c->n_bands, true, tau, rb, re));
+    } else {
+        TimerScope t(c, T_PREP);
+        hipLaunchKernelGGL(cb_bounds_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream,
+                           c->d_cards, n, tau, c->mode == SELHIP_MODE_CB_SMH ? 1 : 0, row_map(c, rb, re), c->ecard.p, c->hi.p, pc0,
+                           (c->p == 14 && c->group_stage2) ? c->csr_cnt.p : nullptr, (int)c->cand_begin);
+        HIPCHK(&c->err, hipGetLastError());
+    }
 
     const int chunks = pipeline_chunks(c);
     c->n_chunks_last = chunks;
