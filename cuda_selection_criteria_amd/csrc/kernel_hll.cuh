@@ -258,6 +258,19 @@ void hll_union_hist_runs_kernel(const uint8_t* __restrict__ hll, const selhip_in
     }
 }
 
+// frame_results_kernel: the result hand-over for a fixed-size collective in ONE launch -- record 0 of `dst` = {count, 0}
+// (the device-side counter: the host need not know it yet), then min(count, cap) result records.
+__global__ __launch_bounds__(kBlock)
+void frame_results_kernel(const selhip_pair_t* __restrict__ results, const u64* __restrict__ n_results, u64 results_cap,
+                          u64 cap_records, uint4* __restrict__ dst) {
+    const u64 cnt_all = *n_results;
+    u64 cnt = cnt_all < cap_records ? cnt_all : cap_records;
+    if (cnt > results_cap) cnt = results_cap;
+    const uint4* src = reinterpret_cast<const uint4*>(results);               // 16-byte records
+    if (blockIdx.x == 0 && threadIdx.x == 0) dst[0] = make_uint4((uint32_t)cnt_all, (uint32_t)(cnt_all >> 32), 0u, 0u);
+    for (u64 j = (u64)blockIdx.x * kBlock + threadIdx.x; j < cnt; j += (u64)gridDim.x * kBlock) dst[1 + j] = src[j];
+}
+
 // ---------------------------------------------------------------------------------------------
 // ertl_select_kernel: one LANE per histogram.  The 64 histograms of a wave are staged in LDS
 // (pitch 65 -> conflict-free) because the estimator indexes them with run-time k.

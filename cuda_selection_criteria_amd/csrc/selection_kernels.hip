@@ -1151,11 +1151,11 @@ int selhip_ctx_copy_results_framed_async(selhip_ctx* c, void* d_dst, int64_t cap
     if (!c->pending && !c->have_run) return SELHIP_E_STATE;
     if (!c->results.p || !c->pc.p) return SELHIP_E_STATE;
     HIPCHK(&c->err, hipSetDevice(c->device));
-    HIPCHK(&c->err, hipMemcpyAsync(d_dst, &c->pc.p->n_results, sizeof(u64), hipMemcpyDeviceToDevice, c->stream));
-    const int64_t cnt = std::min<int64_t>((int64_t)c->results.cap, cap_records);
-    if (cnt > 0)
-        HIPCHK(&c->err, hipMemcpyAsync((char*)d_dst + sizeof(selhip_pair_t), c->results.p, (size_t)cnt * sizeof(selhip_pair_t),
-                                       hipMemcpyDeviceToDevice, c->stream));
+    if ((uintptr_t)d_dst & 15) { set_err(&c->err, "frame buffer must be 16-byte aligned"); return SELHIP_E_BADARG; }
+    static_assert(sizeof(selhip_pair_t) == 16, "frame records are 16 bytes");
+    hipLaunchKernelGGL(frame_results_kernel, dim3(256), dim3(kBlock), 0, c->stream, c->results.p, &c->pc.p->n_results,
+                       (u64)c->results.cap, (u64)cap_records, (uint4*)d_dst);
+    HIPCHK(&c->err, hipGetLastError());
     return SELHIP_OK;
 }
 

@@ -191,9 +191,9 @@ int selhip_ctx_copy_results(selhip_ctx* ctx, selhip_pair_t* d_dst, int64_t cap);
  * d_dst must hold cap_records + 1 records.  Returns SELHIP_E_OVERFLOW (after copying cap_records) if count > cap. */
 int selhip_ctx_copy_results_framed(selhip_ctx* ctx, void* d_dst, int64_t cap_records);
 /* The same frame, enqueued BEHIND a pass that is still running (between selhip_ctx_run_async and selhip_ctx_finish), so
- * that the caller can also enqueue its collective before it waits: the count is not known on the host yet, so the header
- * is copied from the device-side counter and the payload copy always moves cap_records records (<= the result
- * capacity).  After selhip_ctx_finish the caller checks selhip_ctx_result_count() <= cap_records and
+ * that the caller can also enqueue its collective before it waits: the count is not known on the host yet, so one small
+ * kernel reads the device-side counter, writes the header and copies min(count, cap_records) records (d_dst 16-byte
+ * aligned).  After selhip_ctx_finish the caller checks selhip_ctx_result_count() <= cap_records and
  * selhip_ctx_last_attempts() == 1 (an overflowing internal list makes finish repeat the pass, which would leave the
  * frame stale) and otherwise frames again. */
 int selhip_ctx_copy_results_framed_async(selhip_ctx* ctx, void* d_dst, int64_t cap_records);
