@@ -194,8 +194,8 @@ __device__ __forceinline__ void join16_one_query(const uint32_t (&c)[ND], const 
     }
 }
 
-template <int ND, bool DB>
-__global__ __launch_bounds__(kBlock)
+template <int ND, bool DB, int WPB>
+__global__ __launch_bounds__(WPB * kWave)
 void sig16_join_kernel(const uint32_t* __restrict__ sigP, int n, int n_pad,
                        const int* __restrict__ hi, const PassCounters* __restrict__ pc_in,
                        RowMap rm, int n_tiles, int group_base, int qt,
@@ -203,7 +203,7 @@ void sig16_join_kernel(const uint32_t* __restrict__ sigP, int n, int n_pad,
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
     const int tile = blockIdx.x % n_tiles;
-    const int grp = group_base + (blockIdx.x / n_tiles) * kWavesPerBlock + wave;
+    const int grp = group_base + (blockIdx.x / n_tiles) * WPB + wave;
     const int k_base = grp * kWave;
     if (k_base >= n) return;
     const int z0 = pc_in->z0p1 ? pc_in->z0p1 - 1 : n;
@@ -214,7 +214,7 @@ void sig16_join_kernel(const uint32_t* __restrict__ sigP, int n, int n_pad,
     if (i_lo >= i_hi || k_last < z0) return;
     if (hi[i_hi - 1] < k_base) return;                                        // hi is non-decreasing
 
-    __shared__ selhip_int2_t app_lds[kWavesPerBlock * kAppendCap];
+    __shared__ selhip_int2_t app_lds[WPB * kAppendCap];
     WaveAppender app;
     app.init(app_lds, wave, pre, pre_cap, &pc->n_pre);
     const int k = k_base + lane;                                              // < n_pad

@@ -146,6 +146,7 @@ struct selhip_ctx {
     int il_block = 128, il_parts = 1, il_part = 0;    // row interleave (selhip_ctx_set_row_interleave); il_parts 1 = contiguous
     int hist_run = 1, hist_blocks = kHistSpanBlocks;   // stage 2a: pairs per task, one-wave blocks (multiple of 8)
     int verify_fb = 0;                  // test hook: force the collision fallback of verify16_kernel
+    int join_wpb = 1;                   // 16-bit join: waves per block (1: finest dispatch granularity, 126 vs 131 us at cfg3; or 4)
     int join_db = 1;                    // 16-bit join: double-buffered query batches
     int join_bits = 16;                 // signature width of the all-pairs join: 16 (packed, + 32-bit filter) or 32
     int join_qt = 128;                  // query rows per signature-join block (multiple of 16); 16-bit join: 96..128 best at cfg3, 128..256 at cfg4
@@ -331,24 +332,29 @@ hipError_t launch_join(selhip_ctx* c, const StageIO& io, int n_pad, int rb, int 
     return hipGetLastError();
 }
 
-template <int ND, bool DB>
-hipError_t launch_join16(selhip_ctx* c, const StageIO& io, int n_pad, int rb, int re) {
+template <int ND, bool DB, int WPB>
+hipError_t launch_join16_w(selhip_ctx* c, const StageIO& io, int n_pad, int rb, int re) {
     const int n = (int)c->n;
     const int qt = c->join_qt;
     const RowMap rm = row_map(c, rb, re);
     const long long n_tiles_ll = rm.n_tiles(qt);
     if (n_tiles_ll > 0x7FFFFFFFll) return hipErrorInvalidValue;
     const int n_tiles = (int)n_tiles_ll;
-    const int group_base = (std::max(rb + 1, (int)c->cand_begin) / kWave / kWavesPerBlock) * kWavesPerBlock;   // candidates k > row_begin, k >= cand_begin
+    const int group_base = (std::max(rb + 1, (int)c->cand_begin) / kWave / WPB) * WPB;   // candidates k > row_begin, k >= cand_begin
     const int n_groups = (n + kWave - 1) / kWave - group_base;
-    const int n_gblocks = (n_groups + kWavesPerBlock - 1) / kWavesPerBlock;
+    const int n_gblocks = (n_groups + WPB - 1) / WPB;
     if (n_tiles <= 0 || n_gblocks <= 0) return hipSuccess;
     const long long blocks = (long long)n_tiles * n_gblocks;
     if (blocks > 0x7FFFFFFFll) return hipErrorInvalidValue;
-    hipLaunchKernelGGL((sig16_join_kernel<ND, DB>), dim3((unsigned)blocks), dim3(kBlock), 0, io.st,
+    hipLaunchKernelGGL((sig16_join_kernel<ND, DB, WPB>), dim3((unsigned)blocks), dim3(WPB * kWave), 0, io.st,
                        c->sigP.p, n, n_pad, c->hi.p, c->pc.p, rm, n_tiles, group_base, qt,
                        io.cand, io.cap, io.pc);
     return hipGetLastError();
+}
+
+template <int ND, bool DB>
+hipError_t launch_join16(selhip_ctx* c, const StageIO& io, int n_pad, int rb, int re) {
+    return c->join_wpb == 1 ? launch_join16_w<ND, DB, 1>(c, io, n_pad, rb, re) : launch_join16_w<ND, DB, 4>(c, io, n_pad, rb, re);
 }
 
 // sig_build with the pass's bounds computation riding in its first blocks (with_bounds) or alone
@@ -853,6 +859,11 @@ int selhip_ctx_set_param(selhip_ctx* c, const char* name, int value) {
         return SELHIP_OK;
     }
     if (!std::strcmp(name, "verify_fb")) { c->verify_fb = value != 0; return SELHIP_OK; }
+    if (!std::strcmp(name, "join_wpb")) {
+        if (value != 1 && value != 4) { set_err(&c->err, "join_wpb must be 1 or 4"); return SELHIP_E_BADARG; }
+        c->join_wpb = value;
+        return SELHIP_OK;
+    }
     if (!std::strcmp(name, "join_db")) { c->join_db = value != 0; return SELHIP_OK; }
     if (!std::strcmp(name, "join_bits")) {
         if (value != 16 && value != 32) { set_err(&c->err, "join_bits must be 16 or 32"); return SELHIP_E_BADARG; }

@@ -129,6 +129,7 @@ int selhip_ctx_set_candidate_begin(selhip_ctx* ctx, int64_t k_min);
  *   "join_bits"   16 (default): all-pairs join on 16-bit band signatures packed two per dword, its matches cut back to the
  *                 32-bit candidate set during verification; 32: join on the 32-bit signatures directly
  *   "join_db"     1 (default) / 0: double-buffered query batches in the 16-bit join
+ *   "join_wpb"    waves per block of the 16-bit join: 1 (default) or 4
  *   "hist_run"    pairs a wave of stage 2a takes at a time (default 1);  "hist_blocks"  its one-wave blocks (multiple of 8)
  *   "verify_fb"   test hook: 1 sends every candidate through the hash-collision fallback of the verification */
 int selhip_ctx_set_param(selhip_ctx* ctx, const char* name, int value);

@@ -10,9 +10,9 @@ for wl in sys.argv[1:] or ("cfg3", "cfg4"):
     hll, aux, cards, _, _ = pkg.synth_device(cfg)
     r, b = pkg.banding(cfg.m, cfg.tau)
     sel = pkg.Selector(0); sel.attach(hll, aux, cards)
-    for bits, db in ((16, 1),):
-        sel.set_param("join_bits", bits); sel.set_param("join_db", db)
-        for qt in (64, 96, 128, 160, 192):
+    for bits, db in ((16, 4), (16, 1)):
+        sel.set_param("join_bits", bits); sel.set_param("join_wpb", db)
+        for qt in (64, 96, 128):
             sel.set_param("join_qt", qt)
             for _ in range(2): sel.run(cfg.tau, pkg.MODE_SMH, r, b, algo=pkg.ALGO_SIG, fetch=False)
             st = sel.stats()

@@ -260,6 +260,7 @@ def test_join_and_histogram_variants(oracle):
             cand = None
             for bits, db, fb in ((16, 1, 0), (16, 0, 0), (32, 0, 0), (16, 1, 1), (16, 0, 1)):
                 sel.set_param("join_bits", bits); sel.set_param("join_db", db); sel.set_param("verify_fb", fb)
+                sel.set_param("join_wpb", 4 if fb else 1)
                 assert_same_pairs(sel.run(tau, MODE_CB_SMH, r, b, algo=ALGO_SIG), want)
                 s = sel.stats()
                 assert s["evaluated"] == st["evaluated"] and s["survivors"] == st["survivors"]
@@ -268,11 +269,11 @@ def test_join_and_histogram_variants(oracle):
                 assert s["survivors"] == st_all["survivors"]
                 cand = s["candidates"] if cand is None else cand
                 assert s["candidates"] == cand          # the 32-bit candidate set is the same whichever join produced it
-            sel.set_param("join_bits", 16); sel.set_param("join_db", 1); sel.set_param("verify_fb", 0)
+            sel.set_param("join_bits", 16); sel.set_param("join_db", 1); sel.set_param("verify_fb", 0); sel.set_param("join_wpb", 1)
             for run, blocks in ((1, 8), (3, 64), (8, 2048), (1024, 16384), (1, 16384)):
                 sel.set_param("hist_run", run); sel.set_param("hist_blocks", blocks)
                 assert_same_pairs(sel.run(tau, MODE_CB_SMH, r, b), want)
-            for bad in (("join_bits", 24), ("hist_blocks", 12), ("hist_run", 0), ("no_such_param", 1)):
+            for bad in (("join_bits", 24), ("join_wpb", 2), ("hist_blocks", 12), ("hist_run", 0), ("no_such_param", 1)):
                 with pytest.raises(pkg.SelhipError):
                     sel.set_param(*bad)
 
