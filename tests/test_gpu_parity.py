@@ -532,6 +532,35 @@ def test_result_frames_on_the_device(oracle):
         assert int(small.cpu().numpy()[0, 0]) == len(want) and sel.result_count() > 3
 
 
+def test_event_timing_levels(oracle):
+    """selhip_ctx_timing: level 1 times every kernel scope, level 2 only the dominant stage-1 kernel ("join" for the signature
+    algorithms, "stage1" for the stream kernel), 0 nothing; figures are per pass"""
+    cfg = make_golden.GOLDEN_SYNTH["synth_flat_n300_m512"]
+    hll, aux, cards, _, _ = sorted_set(cfg, oracle)
+    r, b = pkg.banding(cfg.m, 0.8)
+    with Selector(0) as sel:
+        sel.upload(hll, aux, cards)
+        sel.run(0.8, MODE_SMH, r, b, fetch=False)
+        sel.timing(2)
+        for _ in range(3):
+            sel.run(0.8, MODE_SMH, r, b, fetch=False)
+        assert sel.kernel_ms("join") > 0 and sel.kernel_launches("join") == 1.0
+        assert sel.kernel_ms("hist") < 0 and sel.kernel_ms("select") < 0 and sel.kernel_ms("total") < 0
+        sel.timing(2)
+        for _ in range(2):
+            sel.run(0.8, MODE_SMH, r, b, algo=ALGO_STREAM, fetch=False)
+        assert sel.kernel_ms("stage1") > 0 and sel.kernel_ms("join") < 0
+        sel.timing(1)
+        for _ in range(2):
+            sel.run(0.8, MODE_SMH, r, b, fetch=False)
+        for name in ("sigbuild", "join", "verify", "stage1", "group", "hist", "select", "total"):
+            assert sel.kernel_ms(name) > 0, name
+        assert sel.kernel_ms("total") >= sel.kernel_ms("join") + sel.kernel_ms("hist")
+        sel.timing(0)
+        sel.run(0.8, MODE_SMH, r, b, fetch=False)
+        assert sel.kernel_ms("join") < 0
+
+
 def test_unsorted_cards_rejected(oracle):
     cfg = SynthConfig("unsorted", 50, 128, 0.9, 5, n_sh_lo=3000, n_sh_hi=3000)
     hll, aux, cards, _, _ = sorted_set(cfg, oracle)
