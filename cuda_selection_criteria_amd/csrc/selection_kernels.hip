@@ -1072,7 +1072,8 @@ int selhip_ctx_finish(selhip_ctx* c) {
         if (pc.n_results > c->results.cap) { res_cap = (size_t)(pc.n_results + pc.n_results / 8 + 1024); grow = true; }
         if (!grow) {
             c->last = pc; c->pending = false; c->have_run = true; c->last_attempts = attempt + 1;
-            if (c->timing) drain_timers(c);
+            // (event pairs are read lazily -- selhip_ctx_kernel_ms / _timing / destroy -- so that a timed run does not stall the
+            // host between passes; a pass records at most ~20 of them)
             return SELHIP_OK;
         }
         // an output list was too small: counts are exact, so grow once and repeat the pass
@@ -1184,6 +1185,7 @@ int selhip_ctx_timing(selhip_ctx* c, int enable) {
 
 double selhip_ctx_kernel_ms(const selhip_ctx* c, const char* name) {
     if (!c || !name) return -1.0;
+    if (!c->pending) drain_timers(const_cast<selhip_ctx*>(c));
     const long passes = c->timed_passes;
     for (int t = 0; t < T_COUNT; ++t)
         if (!std::strcmp(name, kTimerNames[t]))
@@ -1193,6 +1195,7 @@ double selhip_ctx_kernel_ms(const selhip_ctx* c, const char* name) {
 
 double selhip_ctx_kernel_launches(const selhip_ctx* c, const char* name) {
     if (!c || !name) return -1.0;
+    if (!c->pending) drain_timers(const_cast<selhip_ctx*>(c));
     const long passes = c->timed_passes;
     for (int t = 0; t < T_COUNT; ++t)
         if (!std::strcmp(name, kTimerNames[t]))
