@@ -21,28 +21,47 @@ __device__ __forceinline__ u64 mix64(u64 x) {
 }
 
 // sig_build_kernel: one thread per bucket, coalesced 8-B loads; the r lanes of a band add their position-salted
-// mixes with xor-shuffles (r <= 64) -- or one thread walks the band (r > 64).  Writes both layouts:
+// mixes with DPP row shifts (r <= 16) or xor-shuffles (r <= 64) -- or one thread walks the band (r > 64).  Writes the layouts:
 //   sigQ[g][NB] (genome-major), sigT[b][n_pad] (band-major, lane = candidate) and sigP[b/2][n_pad]: the top 16 bits of
 //   the signatures of bands 2d (low half) and 2d+1 (high half) packed in one dword, for the 16-bit join.
+template <int S>
+__device__ __forceinline__ uint32_t dpp_row_shr(uint32_t x) {
+    // DPP row_shr:S -- lane i of a 16-lane row reads lane i-S of the row, 0 for i < S
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x110 + S, 0xF, 0xF, true);
+}
+
+// signature of a band = xor of the two 32-bit halves of  sum_j mix64(v_j + salt_j)  taken half by half (no carry between
+// the halves, so that the lanes of a band can add them with 32-bit DPP shifts).  With m and nb powers of two (always, for the
+// all-pairs joins) bucket index -> (genome, band, position) is shifts and masks instead of 64-bit divisions.
 __device__ __forceinline__ void sig_build_body(long long block, const u64* __restrict__ aux, int n, int m, int r, int nb, int n_pad,
                                                uint32_t* __restrict__ sigQ, uint32_t* __restrict__ sigT, uint32_t* __restrict__ sigP) {
     uint16_t* const sigP16 = reinterpret_cast<uint16_t*>(sigP);
+    // r is a power of two; m and nb are too for the all-pairs joins (sig_supported) but not necessarily for the sort-based join
+    const bool pow2 = (m & (m - 1)) == 0 && (nb & (nb - 1)) == 0;
+    const int lr = __builtin_ctz((unsigned)r), lm = __builtin_ctz((unsigned)m);
     if (r <= kWave) {
         const long long t = block * kBlock + threadIdx.x;                      // global bucket index
         const long long total = (long long)n * m;
-        u64 h = 0;
-        int j = 0;
+        uint32_t hl = 0, hh = 0;
+        const int j = (int)(t & (r - 1));                                      // position inside the band
         if (t < total) {
-            j = (int)(t % r);                                                  // position inside the band
-            h = mix64(aux[t] + 0x9E3779B97F4A7C15ull * (u64)(j + 1));
+            const u64 x = mix64(aux[t] + 0x9E3779B97F4A7C15ull * (u64)(j + 1));
+            hl = (uint32_t)x; hh = (uint32_t)(x >> 32);
         }
-        for (int s = 1; s < r; s <<= 1) {                                      // r is a power of two here
-            h += __shfl_xor(h, s, kWave);
+        int writer = r - 1;                                                    // the band's lane that ends up with the sums
+        if (r <= 16) {                                                         // a band lies inside one 16-lane row: prefix adds by DPP shifts
+            if (r > 1) { hl += dpp_row_shr<1>(hl); hh += dpp_row_shr<1>(hh); }
+            if (r > 2) { hl += dpp_row_shr<2>(hl); hh += dpp_row_shr<2>(hh); }
+            if (r > 4) { hl += dpp_row_shr<4>(hl); hh += dpp_row_shr<4>(hh); }
+            if (r > 8) { hl += dpp_row_shr<8>(hl); hh += dpp_row_shr<8>(hh); }
+        } else {
+            for (int s = 1; s < r; s <<= 1) { hl += __shfl_xor(hl, s, kWave); hh += __shfl_xor(hh, s, kWave); }
+            writer = 0;
         }
-        if (t < total && j == 0) {
-            const int g = (int)(t / m);
-            const int b = (int)((t % m) / r);
-            const uint32_t sig = (uint32_t)(h ^ (h >> 32));
+        if (t < total && j == writer) {
+            const int g = pow2 ? (int)(t >> lm) : (int)(t / m);
+            const int b = (pow2 ? (int)(t & (m - 1)) : (int)(t % m)) >> lr;
+            const uint32_t sig = hl ^ hh;
             sigQ[(long long)g * nb + b] = sig;
             sigT[(long long)b * n_pad + g] = sig;
             sigP16[((long long)(b >> 1) * n_pad + g) * 2 + (b & 1)] = (uint16_t)(sig >> 16);
@@ -50,11 +69,15 @@ __device__ __forceinline__ void sig_build_body(long long block, const u64* __res
     } else {
         const long long t = block * kBlock + threadIdx.x;                      // (genome, band)
         if (t >= (long long)n * nb) return;
-        const int g = (int)(t / nb), b = (int)(t % nb);
-        const u64* v = aux + (long long)g * m + (long long)b * r;
-        u64 h = 0;
-        for (int j = 0; j < r; ++j) h += mix64(v[j] + 0x9E3779B97F4A7C15ull * (u64)(j + 1));
-        const uint32_t sig = (uint32_t)(h ^ (h >> 32));
+        const int g = pow2 ? (int)(t >> __builtin_ctz((unsigned)nb)) : (int)(t / nb);
+        const int b = pow2 ? (int)(t & (nb - 1)) : (int)(t % nb);
+        const u64* v = aux + (long long)g * m + ((long long)b << lr);
+        uint32_t hl = 0, hh = 0;
+        for (int j = 0; j < r; ++j) {
+            const u64 x = mix64(v[j] + 0x9E3779B97F4A7C15ull * (u64)(j + 1));
+            hl += (uint32_t)x; hh += (uint32_t)(x >> 32);
+        }
+        const uint32_t sig = hl ^ hh;
         sigQ[(long long)g * nb + b] = sig;
         sigT[(long long)b * n_pad + g] = sig;
         sigP16[((long long)(b >> 1) * n_pad + g) * 2 + (b & 1)] = (uint16_t)(sig >> 16);
