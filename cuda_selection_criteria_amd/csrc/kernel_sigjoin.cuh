@@ -241,9 +241,14 @@ void sig16_join_kernel(const uint32_t* __restrict__ sigP, int n, int n_pad,
     WaveAppender app;
     app.init(app_lds, wave, pre, pre_cap, &pc->n_pre);
     const int k = k_base + lane;                                              // < n_pad
+    // sigP through a buffer resource: the band's row offset d * n_pad * 4 rides in the instruction's scalar offset and the
+    // lane's column in its 32-bit vector offset, so a load costs no 64-bit address arithmetic on the vector unit (it was
+    // ~7 % of the kernel's VALU instructions); out-of-range offsets read 0 instead of faulting
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(sigP), 0, ND * n_pad * 4, 0x00020000);
+    const int row_bytes = n_pad * 4;
     uint32_t c[ND];
 #pragma unroll
-    for (int d = 0; d < ND; ++d) c[d] = sigP[(long long)d * n_pad + k];
+    for (int d = 0; d < ND; ++d) c[d] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rsrc, k * 4, d * row_bytes, 0);
 
 #define SELHIP_JQ16(Q, I0) \
     { join16_one_query<ND, 0>(c, Q, (I0) + 0, i_hi, k, lane, z0, n, hi, app); join16_one_query<ND, 1>(c, Q, (I0) + 1, i_hi, k, lane, z0, n, hi, app); \
@@ -255,8 +260,8 @@ void sig16_join_kernel(const uint32_t* __restrict__ sigP, int n, int n_pad,
       join16_one_query<ND, 12>(c, Q, (I0) + 12, i_hi, k, lane, z0, n, hi, app); join16_one_query<ND, 13>(c, Q, (I0) + 13, i_hi, k, lane, z0, n, hi, app); \
       join16_one_query<ND, 14>(c, Q, (I0) + 14, i_hi, k, lane, z0, n, hi, app); join16_one_query<ND, 15>(c, Q, (I0) + 15, i_hi, k, lane, z0, n, hi, app); }
 #define SELHIP_LOADQ(Q, I0) \
-    { const int qi_ = min((I0) + (lane & 15), n_pad - 1); \
-      _Pragma("unroll") for (int d = 0; d < ND; ++d) Q[d] = sigP[(long long)d * n_pad + qi_]; }
+    { const int qo_ = min((I0) + (lane & 15), n_pad - 1) * 4; \
+      _Pragma("unroll") for (int d = 0; d < ND; ++d) Q[d] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rsrc, qo_, d * row_bytes, 0); }
 
     if constexpr (DB) {
         // two register sets: the next 16 queries are in flight while the current 16 are compared
