@@ -316,11 +316,11 @@ void verify_kernel(const u64* __restrict__ aux, int m, int n_rows, int n_bands,
 // single-address atomic per wave, ~85 of those per microsecond); one lane per pair for step 1 (uncoalesced loads: cfg4
 // verification 90 -> 370 us); literal check in place on each batch's few passing lanes (cfg4 355 us) or on lanes packed
 // through LDS (cfg4 205 us, cfg3 60 us).
-// Output: the survivors of a block's 1024 pairs are gathered in LDS and appended with ONE global atomic per block and
+// Output: the survivors of a block's 512 pairs (256: 27 us, 512: 24 us, 1024: 26 us at cfg3) are gathered in LDS and appended with ONE global atomic per block and
 // batch (plus one for the candidate tally): appends are single-address atomics, ~85 per microsecond on this part, and a
 // per-wave append (1 500 waves at cfg3) costs more than the whole check (52 us vs 15 us).
 // force_fallback (test hook): treat every first-band comparison as a collision.
-constexpr int kVerifyBlock = 1024;
+constexpr int kVerifyBlock = 512;
 
 __global__ __launch_bounds__(kVerifyBlock)
 void verify16_kernel(const u64* __restrict__ aux, int m, int n_rows, int n_bands, const uint32_t* __restrict__ sigQ,

@@ -391,7 +391,7 @@ hipError_t launch_stage1_sig(selhip_ctx* c, const StageIO& io, int n_rows, int n
         if (e != hipSuccess) return e;
         // the 16-bit matches were staged in the candidate list; survivors go to the survivor list as usual
         TimerScope t(c, T_VERIFY, io.st);
-        hipLaunchKernelGGL(verify16_kernel, dim3(512), dim3(kVerifyBlock), 0, io.st, c->d_aux, c->m, n_rows, n_bands, c->sigQ.p,
+        hipLaunchKernelGGL(verify16_kernel, dim3(1024), dim3(kVerifyBlock), 0, io.st, c->d_aux, c->m, n_rows, n_bands, c->sigQ.p,
                            io.cand, &io.pc->n_pre, io.cap, io.surv, io.cap, io.pc, c->verify_fb, io.row_cnt);
         return hipGetLastError();
     } else {
