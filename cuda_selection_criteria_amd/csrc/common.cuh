@@ -23,7 +23,8 @@ struct PassCounters {
     u64 n_candidates;    // ALGO_SIG: signature-join candidates
     u64 n_aux_in;        // pairs handed to the auxiliary-HLL criterion (hll_a / hll_an)
     u64 n_final;         // pairs handed to the final HLL-14 Jaccard stage
-    u64 n_pre;           // ALGO_SIG, 16-bit join: pairs with an equal 16-bit band signature (filtered down to n_candidates)
+    u64 n_pre;           // ALGO_SIG, 16-bit join: pairs with an equal 16-bit band signature (filtered down to n_candidates); sum over the append segments
+    u64 n_pre_segmax;    //   the fullest append segment's count (overflow test: every segment has cap / kAppendSegs slots)
     int z0p1;            // 1 + first rank with e != 0; 0 (the memset value) = none, i.e. z0 = n
     int unsorted;        // set if cards are not ascending
 };
@@ -67,6 +68,13 @@ struct RowMap {
 // (45 000 survivors = 0.5 ms -- measured: it was THE cost of the first signature-join kernels).
 // ---------------------------------------------------------------------------------------------
 constexpr int kAppendCap = 2 * kWave;          // count < 64 before a push, a push adds <= 64
+
+// The all-pairs join appends through kAppendSegs INDEPENDENT lists (own counter, own slice of the output array; a block
+// uses segment blockIdx % kAppendSegs).  Measured (gpurun_out/r02/join_dbg.txt, PMC in DESIGN.md section 4): with ONE counter
+// the join of cfg4 was bound by the ~87 returning atomics per microsecond a single address sustains -- every wave flushes
+// at least once, 153 000 waves = 1.8 ms of a 2.1 ms kernel, and halving the tile height doubled the kernel time.
+constexpr int kAppendSegs = 64;
+constexpr int kSegStride = 16;                 // u64 slots between two segment counters (128 B: one cache line each)
 
 struct WaveAppender {
     selhip_int2_t* buf;        // this wave's LDS staging area [kAppendCap]

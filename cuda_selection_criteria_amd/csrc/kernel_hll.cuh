@@ -126,7 +126,8 @@ void csr_fill_kernel(const selhip_int2_t* __restrict__ pairs, const u64* __restr
     if (n > cap) n = cap;
     for (u64 j = (u64)blockIdx.x * kBlock + threadIdx.x; j < n; j += (u64)gridDim.x * kBlock) {
         const selhip_int2_t pr = pairs[j];
-        grouped[start[pr.x] + atomicAdd(&fill[pr.x], 1)] = pr;
+        const u64 pos = (u64)start[pr.x] + (u64)atomicAdd(&fill[pr.x], 1);
+        if (pos < cap) grouped[pos] = pr;                                    // (always true when the counts tallied min(n, cap) pairs)
     }
 }
 

@@ -23,7 +23,8 @@ __device__ __forceinline__ u64 mix64(u64 x) {
 // sig_build_kernel: one thread per bucket, coalesced 8-B loads; the r lanes of a band add their position-salted
 // mixes with DPP row shifts (r <= 16) or xor-shuffles (r <= 64) -- or one thread walks the band (r > 64).  Writes the layouts:
 //   sigQ[g][NB] (genome-major), sigT[b][n_pad] (band-major, lane = candidate) and sigP[b/2][n_pad]: the top 16 bits of
-//   the signatures of bands 2d (low half) and 2d+1 (high half) packed in one dword, for the 16-bit join.
+//   the signatures of bands 2d (low half) and 2d+1 (high half) packed in one dword, for the 16-bit join -- plus sigG[g][NB/2],
+//   the same packed dwords genome-major (the query side of sigs_join_kernel, read through the scalar cache).
 template <int S>
 __device__ __forceinline__ uint32_t dpp_row_shr(uint32_t x) {
     // DPP row_shr:S -- lane i of a 16-lane row reads lane i-S of the row, 0 for i < S
@@ -34,8 +35,11 @@ __device__ __forceinline__ uint32_t dpp_row_shr(uint32_t x) {
 // the halves, so that the lanes of a band can add them with 32-bit DPP shifts).  With m and nb powers of two (always, for the
 // all-pairs joins) bucket index -> (genome, band, position) is shifts and masks instead of 64-bit divisions.
 __device__ __forceinline__ void sig_build_body(long long block, const u64* __restrict__ aux, int n, int m, int r, int nb, int n_pad,
-                                               uint32_t* __restrict__ sigQ, uint32_t* __restrict__ sigT, uint32_t* __restrict__ sigP) {
+                                               uint32_t* __restrict__ sigQ, uint32_t* __restrict__ sigT, uint32_t* __restrict__ sigP,
+                                               uint32_t* __restrict__ sigG) {
     uint16_t* const sigP16 = reinterpret_cast<uint16_t*>(sigP);
+    uint16_t* const sigG16 = reinterpret_cast<uint16_t*>(sigG);          // genome-major twin of sigP: [g][(nb + 1) / 2] dwords
+    const long long g_pitch = 2ll * ((nb + 1) / 2);
     // r is a power of two; m and nb are too for the all-pairs joins (sig_supported) but not necessarily for the sort-based join
     const bool pow2 = (m & (m - 1)) == 0 && (nb & (nb - 1)) == 0;
     const int lr = __builtin_ctz((unsigned)r), lm = __builtin_ctz((unsigned)m);
@@ -65,6 +69,7 @@ __device__ __forceinline__ void sig_build_body(long long block, const u64* __res
             sigQ[(long long)g * nb + b] = sig;
             sigT[(long long)b * n_pad + g] = sig;
             sigP16[((long long)(b >> 1) * n_pad + g) * 2 + (b & 1)] = (uint16_t)(sig >> 16);
+            sigG16[(long long)g * g_pitch + b] = (uint16_t)(sig >> 16);
         }
     } else {
         const long long t = block * kBlock + threadIdx.x;                      // (genome, band)
@@ -81,6 +86,7 @@ __device__ __forceinline__ void sig_build_body(long long block, const u64* __res
         sigQ[(long long)g * nb + b] = sig;
         sigT[(long long)b * n_pad + g] = sig;
         sigP16[((long long)(b >> 1) * n_pad + g) * 2 + (b & 1)] = (uint16_t)(sig >> 16);
+        sigG16[(long long)g * g_pitch + b] = (uint16_t)(sig >> 16);
     }
 }
 
@@ -88,14 +94,17 @@ __device__ __forceinline__ void sig_build_body(long long block, const u64* __res
 // waves of binary searches, latency-bound), the others build the signatures -- the bounds then cost nothing on the stream.
 __global__ __launch_bounds__(kBlock)
 void sig_build_kernel(const u64* __restrict__ aux, int n, int m, int r, int nb, int n_pad,
-                      uint32_t* __restrict__ sigQ, uint32_t* __restrict__ sigT, uint32_t* __restrict__ sigP,
+                      uint32_t* __restrict__ sigQ, uint32_t* __restrict__ sigT, uint32_t* __restrict__ sigP, uint32_t* __restrict__ sigG,
                       int bounds_blocks, const double* __restrict__ cards, double tau, int use_cb, RowMap rm,
-                      u64* __restrict__ ecard, int* __restrict__ hi, PassCounters* __restrict__ pc, int* __restrict__ csr_zero, int cand_begin) {
+                      u64* __restrict__ ecard, int* __restrict__ hi, PassCounters* __restrict__ pc, int* __restrict__ csr_zero, int cand_begin,
+                      u64* __restrict__ seg_zero, int seg_zero_n) {
     if ((int)blockIdx.x < bounds_blocks) {
-        cb_bounds_body((int)(blockIdx.x * kBlock + threadIdx.x), cards, n, tau, use_cb, rm, ecard, hi, pc, csr_zero, cand_begin);
+        const int t = (int)(blockIdx.x * kBlock + threadIdx.x);
+        for (int j = t; j < seg_zero_n; j += bounds_blocks * kBlock) seg_zero[j] = 0;      // the join's append-segment counters of this pass
+        cb_bounds_body(t, cards, n, tau, use_cb, rm, ecard, hi, pc, csr_zero, cand_begin);
         return;
     }
-    sig_build_body((long long)blockIdx.x - bounds_blocks, aux, n, m, r, nb, n_pad, sigQ, sigT, sigP);
+    sig_build_body((long long)blockIdx.x - bounds_blocks, aux, n, m, r, nb, n_pad, sigQ, sigT, sigP, sigG);
 }
 
 // sig_join_kernel<NB>: all-pairs "some band signature equal", entirely on the vector unit.
@@ -222,7 +231,7 @@ __global__ __launch_bounds__(WPB * kWave)
 void sig16_join_kernel(const uint32_t* __restrict__ sigP, int n, int n_pad,
                        const int* __restrict__ hi, const PassCounters* __restrict__ pc_in,
                        RowMap rm, int n_tiles, int group_base, int qt,
-                       selhip_int2_t* __restrict__ pre, u64 pre_cap, PassCounters* __restrict__ pc) {
+                       selhip_int2_t* __restrict__ pre, u64 pre_cap, u64* __restrict__ seg_cnt) {
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
     const int tile = blockIdx.x % n_tiles;
@@ -239,7 +248,11 @@ void sig16_join_kernel(const uint32_t* __restrict__ sigP, int n, int n_pad,
 
     __shared__ selhip_int2_t app_lds[WPB * kAppendCap];
     WaveAppender app;
-    app.init(app_lds, wave, pre, pre_cap, &pc->n_pre);
+    {
+        const int seg = blockIdx.x % kAppendSegs;
+        const u64 seg_cap = pre_cap / kAppendSegs;
+        app.init(app_lds, wave, pre + (size_t)seg * seg_cap, seg_cap, seg_cnt + seg * kSegStride);
+    }
     const int k = k_base + lane;                                              // < n_pad
     // sigP through a buffer resource: the band's row offset d * n_pad * 4 rides in the instruction's scalar offset and the
     // lane's column in its 32-bit vector offset, so a load costs no 64-bit address arithmetic on the vector unit (it was
@@ -286,6 +299,169 @@ void sig16_join_kernel(const uint32_t* __restrict__ sigP, int n, int n_pad,
     app.flush(lane);
 }
 
+// sigl_join_kernel<ND, T, WPB>: the 16-bit join with the QUERY TILE STAGED IN LDS (one tile per workgroup) and broadcast
+// to the lanes by plain LDS reads, so that the per-band work on the vector unit is a plain VOP2 xor plus the packed min.
+// Why (profiles/r02_valu_rate.txt, scripts/microbench/valu_rate.hip): on gfx950 a VGPR-VGPR VOP2 (`v_xor_b32`, `v_and_b32`,
+// `v_add_u32`, `v_min_u16`, `v_fma_f32`) issues every ~2.1 cycles per SIMD once >= 4 waves share it, but ANY instruction with
+// a DPP or SDWA modifier, an SGPR operand, three sources (VOP3) or packed math (VOP3P) costs 4.07 cycles at every occupancy.
+// The DPP form above therefore pays 4.07 (xor_dpp) + 4.07 (pk_min) = 8.1 cycles per dword (two bands) and 64 pairs; a query
+// dword fetched by `s_load` into an SGPR makes the xor cost 4.07 as well (tried: 2.19 vs 2.27 ms at cfg4, no gain).  With
+// the query dword in a VGPR the xor is the 2.1-cycle VOP2 -- 6.2 cycles per dword -- and the only way to put it there without
+// spending vector-unit time is an LDS read whose 64 lanes share one address (`ds_read_b128`, 4 dwords per instruction, no
+// bank conflict): the broadcast moves to the LDS pipe, which the join otherwise leaves idle.
+// Layout: the block copies its tile of query rows (qt rows x ND dwords, genome-major sigG, coalesced 16-B loads) into LDS
+// once; each of its WPB waves holds T groups of 64 candidates in VGPRs (lane = candidate) and walks the rows, reading row
+// chunks of 16 dwords one chunk ahead of the chunk being compared (two register sets).  Results identical to
+// sig16_join_kernel (same predicate on the same signatures).
+template <int ND, int T, int OFF, int CNT>
+__device__ __forceinline__ void joinl_accum(us2_t (&acc)[T][4], const uint32_t (&c)[T][ND], const uint32_t (&q)[CNT]) {
+#pragma unroll
+    for (int d = 0; d < CNT; d += 4) {
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+            uint32_t x[4];
+#pragma unroll
+            for (int a = 0; a < 4; ++a) x[a] = c[t][OFF + d + a] ^ q[d + a];
+#pragma unroll
+            for (int a = 0; a < 4; ++a) acc[t][a] = __builtin_elementwise_min(acc[t][a], __builtin_bit_cast(us2_t, x[a]));
+        }
+    }
+}
+
+template <int T>
+__device__ __forceinline__ void joinl_reset(us2_t (&acc)[T][4]) {
+#pragma unroll
+    for (int t = 0; t < T; ++t)
+#pragma unroll
+        for (int a = 0; a < 4; ++a) acc[t][a] = us2_t{0xFFFF, 0xFFFF};
+}
+
+template <int T>
+__device__ __forceinline__ void joinl_test(const us2_t (&acc)[T][4], int i, int k0, int lane, int z0, int n,
+                                           const int* __restrict__ hi, WaveAppender& app) {
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+        const uint32_t mv = __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_elementwise_min(acc[t][0], acc[t][1]),
+                                                                                     __builtin_elementwise_min(acc[t][2], acc[t][3])));
+        const u64 mm = __ballot(min(mv & 0xFFFFu, mv >> 16) == 0u);
+        if (mm) {
+            const int lo = max(i + 1, z0);
+            const int hk = min(hi[i], n - 1);
+            const int k = k0 + t * kWave;
+            app.push(((mm >> lane) & 1ull) && k >= lo && k <= hk, i, k, lane);
+        }
+    }
+}
+
+// CH dwords of a query row from the LDS tile: every lane reads the same address (broadcast)
+template <int CH>
+__device__ __forceinline__ void joinl_load(uint32_t (&q)[CH], const uint32_t* row_chunk) {
+    if constexpr (CH % 4 == 0) {
+        const uint4* p = reinterpret_cast<const uint4*>(row_chunk);
+#pragma unroll
+        for (int j = 0; j < CH / 4; ++j) { const uint4 v = p[j]; q[4 * j] = v.x; q[4 * j + 1] = v.y; q[4 * j + 2] = v.z; q[4 * j + 3] = v.w; }
+    } else {
+#pragma unroll
+        for (int j = 0; j < CH; ++j) q[j] = row_chunk[j];
+    }
+}
+
+constexpr int kJoinTilePadRows = 2;        // look-ahead reads past the last staged row stay inside the allocation
+
+template <int ND, int T, int WPB>
+__global__ __launch_bounds__(WPB * kWave)
+void sigl_join_kernel(const uint32_t* __restrict__ sigP, const uint32_t* __restrict__ sigG, int n, int n_pad,
+                      const int* __restrict__ hi, const PassCounters* __restrict__ pc_in,
+                      RowMap rm, int n_tiles, int group_base, int qt,
+                      selhip_int2_t* __restrict__ pre, u64 pre_cap, u64* __restrict__ seg_cnt) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t joinl_smem[];
+    selhip_int2_t* const app_lds = reinterpret_cast<selhip_int2_t*>(joinl_smem);                  // WPB * kAppendCap records
+    uint32_t* const tile_lds = joinl_smem + WPB * kAppendCap * 2;                                 // (qt + pad) rows x ND dwords
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
+    const int tile = blockIdx.x % n_tiles;
+    const int grp_b = group_base + (blockIdx.x / n_tiles) * (WPB * T);                            // the block's first candidate group
+    // ---- block-uniform part: which rows can meet this block's candidates at all
+    if (grp_b * kWave >= n) return;
+    const int z0 = pc_in->z0p1 ? pc_in->z0p1 - 1 : n;
+    const int kb_last = (grp_b + WPB * T) * kWave - 1;
+    int i_lo, i_end;
+    rm.tile_rows(tile, qt, &i_lo, &i_end);
+    const int ib_hi = min(i_end, kb_last);                                    // need i < k for some lane of the block
+    if (i_lo >= ib_hi || kb_last < z0) return;
+    if (hi[ib_hi - 1] < grp_b * kWave) return;                                // hi is non-decreasing
+    {   // stage the rows [i_lo, ib_hi) of sigG: contiguous, 16-byte aligned (ND is a multiple of 4)
+        const uint4* src = reinterpret_cast<const uint4*>(sigG + (size_t)i_lo * ND);
+        uint4* dst = reinterpret_cast<uint4*>(tile_lds);
+        const int n16 = (ib_hi - i_lo) * (ND / 4);
+        for (int t = threadIdx.x; t < n16; t += WPB * kWave) dst[t] = src[t];
+    }
+    __syncthreads();
+    // ---- per wave (no block-wide synchronisation below)
+    const int k_base = (grp_b + wave * T) * kWave;
+    if (k_base >= n) return;
+    const int k_last = k_base + T * kWave - 1;
+    const int i_hi = min(i_end, k_last);
+    if (i_lo >= i_hi || k_last < z0) return;
+    if (hi[i_hi - 1] < k_base) return;
+
+    WaveAppender app;
+    {
+        const int seg = blockIdx.x % kAppendSegs;
+        const u64 seg_cap = pre_cap / kAppendSegs;
+        app.init(app_lds, wave, pre + (size_t)seg * seg_cap, seg_cap, seg_cnt + seg * kSegStride);
+    }
+    const int k0 = k_base + lane;
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(sigP), 0, ND * n_pad * 4, 0x00020000);
+    const int row_bytes = n_pad * 4;
+    uint32_t c[T][ND];
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+        const int kk = min(k0 + t * kWave, n_pad - 1);                        // lanes past the end repeat the last column (never pushed: k > hk)
+#pragma unroll
+        for (int d = 0; d < ND; ++d) c[t][d] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rsrc, kk * 4, d * row_bytes, 0);
+    }
+    constexpr int CH = ND < 16 ? ND : 16;                                      // dwords per chunk (one register set)
+    constexpr int NCH = ND / CH;                                               // chunks per row: 1 (<= 32 bands), 2 (64), 4 (128)
+    const int rows = i_hi - i_lo;
+    us2_t acc[T][4];
+    uint32_t qa[CH], qb[CH];
+    joinl_load<CH>(qa, tile_lds);
+    if constexpr (NCH == 1) {
+        for (int r = 0; r < rows; r += 2) {
+            joinl_load<CH>(qb, tile_lds + (r + 1) * ND);
+            joinl_reset<T>(acc);
+            joinl_accum<ND, T, 0, CH>(acc, c, qa);
+            joinl_test<T>(acc, i_lo + r, k0, lane, z0, n, hi, app);
+            if (r + 1 >= rows) break;
+            joinl_load<CH>(qa, tile_lds + (r + 2) * ND);
+            joinl_reset<T>(acc);
+            joinl_accum<ND, T, 0, CH>(acc, c, qb);
+            joinl_test<T>(acc, i_lo + r + 1, k0, lane, z0, n, hi, app);
+        }
+    } else {
+        for (int r = 0; r < rows; ++r) {
+            const uint32_t* row = tile_lds + r * ND;
+            joinl_reset<T>(acc);
+            joinl_load<CH>(qb, row + CH);
+            joinl_accum<ND, T, 0, CH>(acc, c, qa);
+            if constexpr (NCH == 2) {
+                joinl_load<CH>(qa, row + ND);                                  // chunk 0 of the next row
+                joinl_accum<ND, T, CH, CH>(acc, c, qb);
+            } else {
+                joinl_load<CH>(qa, row + 2 * CH);
+                joinl_accum<ND, T, CH, CH>(acc, c, qb);
+                joinl_load<CH>(qb, row + 3 * CH);
+                joinl_accum<ND, T, 2 * CH, CH>(acc, c, qa);
+                joinl_load<CH>(qa, row + ND);
+                joinl_accum<ND, T, 3 * CH, CH>(acc, c, qb);
+            }
+            joinl_test<T>(acc, i_lo + r, k0, lane, z0, n, hi, app);
+        }
+    }
+    app.flush(lane);
+}
+
 // verify_kernel: the literal smh_a on every candidate (one lane per candidate), survivors compacted.
 __global__ __launch_bounds__(kBlock)
 void verify_kernel(const u64* __restrict__ aux, int m, int n_rows, int n_bands,
@@ -324,20 +500,28 @@ constexpr int kVerifyBlock = 512;
 
 __global__ __launch_bounds__(kVerifyBlock)
 void verify16_kernel(const u64* __restrict__ aux, int m, int n_rows, int n_bands, const uint32_t* __restrict__ sigQ,
-                     const selhip_int2_t* __restrict__ pre, const u64* __restrict__ n_pre_dev, u64 pre_cap,
+                     const selhip_int2_t* __restrict__ pre_all, const u64* __restrict__ seg_cnt, u64 pre_cap,
                      selhip_int2_t* __restrict__ surv, u64 surv_cap, PassCounters* __restrict__ pc, int force_fallback,
                      int* __restrict__ row_cnt) {
     __shared__ selhip_int2_t out_lds[kVerifyBlock];
     __shared__ uint32_t blk_count, blk_cand;
     __shared__ u64 blk_base;
-    u64 n_pre = *n_pre_dev;
-    if (n_pre > pre_cap) n_pre = pre_cap;
+    // the join's output comes in kAppendSegs lists; block b works on list b % kAppendSegs (gridDim.x is a multiple of kAppendSegs)
+    const int seg = blockIdx.x % kAppendSegs;
+    const u64 seg_cap = pre_cap / kAppendSegs;
+    const selhip_int2_t* __restrict__ pre = pre_all + (size_t)seg * seg_cap;
+    const u64 n_seg = seg_cnt[seg * kSegStride];
+    if (blockIdx.x < kAppendSegs && threadIdx.x == 0 && n_seg) {             // exact totals for the host (overflow test, statistics)
+        atomicAdd(&pc->n_pre, n_seg);
+        atomicMax(&pc->n_pre_segmax, n_seg);
+    }
+    const u64 n_pre = n_seg > seg_cap ? seg_cap : n_seg;
     const int lane = threadIdx.x & (kWave - 1);
     const int sub = lane & 15, quarter = lane >> 4, qshift = quarter * 16;
     const int nq = n_bands >> 2;                                              // 16-byte groups per genome (n_bands % 8 == 0, <= 32)
     if (threadIdx.x == 0) { blk_count = 0; blk_cand = 0; }
     __syncthreads();
-    for (u64 base = (u64)blockIdx.x * kVerifyBlock; base < n_pre; base += (u64)gridDim.x * kVerifyBlock) {
+    for (u64 base = (u64)(blockIdx.x / kAppendSegs) * kVerifyBlock; base < n_pre; base += (u64)(gridDim.x / kAppendSegs) * kVerifyBlock) {
         const u64 j = base + threadIdx.x;
         const bool live = j < n_pre;
         selhip_int2_t pr{0, 0};
@@ -408,8 +592,10 @@ void verify16_kernel(const u64* __restrict__ aux, int m, int n_rows, int n_bands
         if (threadIdx.x < cnt) {
             const u64 dst = blk_base + threadIdx.x;
             const selhip_int2_t q = out_lds[threadIdx.x];
-            if (dst < surv_cap) surv[dst] = q;
-            if (row_cnt) atomicAdd(&row_cnt[q.x], 1);                        // stage 2 grouping: survivors per query row (csr_count)
+            if (dst < surv_cap) {
+                surv[dst] = q;
+                if (row_cnt) atomicAdd(&row_cnt[q.x], 1);                    // stage 2 grouping: survivors per query row, STORED ones only
+            }                                                                //   (like csr_count_kernel: the offsets must stay inside `grouped`)
         }
         __syncthreads();
         if (threadIdx.x == 0) { blk_count = 0; blk_cand = 0; }

@@ -119,6 +119,7 @@ struct selhip_ctx {
     DevBuf<u64> ecard;
     DevBuf<int> hi;
     DevBuf<PassCounters> pc;
+    DevBuf<u64> seg_cnt;                // the join's append-segment counters: (kMaxChunks + 1) x kAppendSegs x kSegStride
     DevBuf<selhip_int2_t> surv;
     DevBuf<uint32_t> counts;
     DevBuf<selhip_pair_t> results;
@@ -129,7 +130,7 @@ struct selhip_ctx {
     DevBuf<uint8_t> own_aux_hll;
     int p_aux = 0;
     int criterion = 0;
-    DevBuf<uint32_t> sigQ, sigT, sigP;  // ALGO_SIG: band signatures, genome-major / band-major / band-major 16-bit pairs
+    DevBuf<uint32_t> sigQ, sigT, sigP, sigG;  // ALGO_SIG: band signatures, genome-major / band-major / band-major 16-bit pairs / genome-major 16-bit pairs
     DevBuf<u64> hj_keys_in, hj_keys_out;   // ALGO_HASHJOIN: (band << 32 | signature) keys, before / after the sort
     DevBuf<int> hj_vals_in, hj_vals_out;   //                genome ranks carried by the keys
     DevBuf<char> hj_tmp;                   //                rocPRIM temporary storage
@@ -146,10 +147,13 @@ struct selhip_ctx {
     int il_block = 128, il_parts = 1, il_part = 0;    // row interleave (selhip_ctx_set_row_interleave); il_parts 1 = contiguous
     int hist_run = 1, hist_blocks = kHistSpanBlocks;   // stage 2a: pairs per task, one-wave blocks (multiple of 8)
     int verify_fb = 0;                  // test hook: force the collision fallback of verify16_kernel
-    int join_wpb = 1;                   // 16-bit join: waves per block (1: finest dispatch granularity, 126 vs 131 us at cfg3; or 4)
+    int join_wpb = 4;                   // 16-bit join: waves per block (DPP form: 1 or 4; LDS form: 4 or 8 -- the waves of a block share the staged query tile)
     int join_db = 1;                    // 16-bit join: double-buffered query batches
     int join_bits = 16;                 // signature width of the all-pairs join: 16 (packed, + 32-bit filter) or 32
-    int join_qt = 128;                  // query rows per signature-join block (multiple of 16); 16-bit join: 96..128 best at cfg3, 128..256 at cfg4
+    int join_q = 1;                     // 16-bit join, query side: 1 = tile staged in LDS, broadcast reads (sigl_join_kernel), 0 = DPP row broadcast (sig16_join_kernel)
+    int init_cap = 0;                   // test hook: initial capacity of the survivor / candidate lists (0 = sized from the workload)
+    int join_qt = 64;                   // query rows per signature-join block (multiple of 16).  With the segmented appends: cfg3 112 / 114 / 127 us at
+                                        // 64 / 96 / 128 rows (finer tiles balance the 1 024 SIMDs better), cfg4 2.12 / 2.10 / 2.07 ms, cfg5 8.31 / 8.16 / 8.20 ms
     bool group_stage2 = true;           // bucket survivors by query row before stage 2a (hll_union_hist_runs_kernel)
 
     // last run parameters (for overflow re-runs)
@@ -207,6 +211,7 @@ struct StageIO {
     u64 cap;
     PassCounters* pc;
     int* row_cnt = nullptr;     // if set, the producer of `surv` also tallies survivors per query row (stage-2 grouping)
+    u64* seg_cnt = nullptr;     // 16-bit join: this launch's kAppendSegs append counters
 };
 
 void drain_timers(selhip_ctx* c) {
@@ -348,12 +353,46 @@ hipError_t launch_join16_w(selhip_ctx* c, const StageIO& io, int n_pad, int rb, 
     if (blocks > 0x7FFFFFFFll) return hipErrorInvalidValue;
     hipLaunchKernelGGL((sig16_join_kernel<ND, DB, WPB>), dim3((unsigned)blocks), dim3(WPB * kWave), 0, io.st,
                        c->sigP.p, n, n_pad, c->hi.p, c->pc.p, rm, n_tiles, group_base, qt,
-                       io.cand, io.cap, io.pc);
+                       io.cand, io.cap, io.seg_cnt);
     return hipGetLastError();
+}
+
+template <int ND, int T, int WPB>
+hipError_t launch_joinl_w(selhip_ctx* c, const StageIO& io, int n_pad, int rb, int re) {
+    const int n = (int)c->n;
+    // tile height: the configured one, capped so that the tile (+ appenders) fits 64 KiB of LDS; a multiple of 16 that divides the
+    // interleave block when rows are interleaved
+    int qt = std::min(c->join_qt, (int)((64 * 1024 - WPB * kAppendCap * sizeof(selhip_int2_t)) / (ND * 4) - kJoinTilePadRows) / 16 * 16);
+    if (c->il_parts > 1) while (c->il_block % qt) qt -= 16;
+    const RowMap rm = row_map(c, rb, re);
+    const long long n_tiles_ll = rm.n_tiles(qt);
+    if (n_tiles_ll > 0x7FFFFFFFll) return hipErrorInvalidValue;
+    const int n_tiles = (int)n_tiles_ll;
+    constexpr int GPB = WPB * T;                                                          // candidate groups per block
+    const int group_base = (std::max(rb + 1, (int)c->cand_begin) / kWave / GPB) * GPB;   // candidates k > row_begin, k >= cand_begin
+    const int n_groups = (n + kWave - 1) / kWave - group_base;
+    const int n_gblocks = (n_groups + GPB - 1) / GPB;
+    if (n_tiles <= 0 || n_gblocks <= 0) return hipSuccess;
+    const long long blocks = (long long)n_tiles * n_gblocks;
+    if (blocks > 0x7FFFFFFFll) return hipErrorInvalidValue;
+    const size_t smem = (size_t)WPB * kAppendCap * sizeof(selhip_int2_t) + (size_t)(qt + kJoinTilePadRows) * ND * 4;
+    if (smem > 64 * 1024) return hipErrorInvalidValue;                                   // join_qt is capped so that this cannot happen
+    hipLaunchKernelGGL((sigl_join_kernel<ND, T, WPB>), dim3((unsigned)blocks), dim3(WPB * kWave), smem, io.st,
+                       c->sigP.p, c->sigG.p, n, n_pad, c->hi.p, c->pc.p, rm, n_tiles, group_base, qt,
+                       io.cand, io.cap, io.seg_cnt);
+    return hipGetLastError();
+}
+
+// (T = 2 groups of candidates per wave -- half the LDS reads -- was measured: 130 VGPRs, 3 waves per SIMD, cfg3 157 vs 127 us,
+// cfg4 2.37 vs 2.07 ms; the template keeps the parameter, only T = 1 is instantiated)
+template <int ND>
+hipError_t launch_joinl(selhip_ctx* c, const StageIO& io, int n_pad, int rb, int re) {
+    return c->join_wpb == 8 ? launch_joinl_w<ND, 1, 8>(c, io, n_pad, rb, re) : launch_joinl_w<ND, 1, 4>(c, io, n_pad, rb, re);
 }
 
 template <int ND, bool DB>
 hipError_t launch_join16(selhip_ctx* c, const StageIO& io, int n_pad, int rb, int re) {
+    if (c->join_q) return launch_joinl<ND>(c, io, n_pad, rb, re);
     return c->join_wpb == 1 ? launch_join16_w<ND, DB, 1>(c, io, n_pad, rb, re) : launch_join16_w<ND, DB, 4>(c, io, n_pad, rb, re);
 }
 
@@ -365,9 +404,10 @@ hipError_t launch_sig_build(selhip_ctx* c, int n_rows, int n_bands, bool with_bo
     const long long threads = n_rows <= kWave ? (long long)n * c->m : (long long)n * n_bands;
     const int bounds_blocks = with_bounds ? (n + kBlock - 1) / kBlock : 0;
     hipLaunchKernelGGL(sig_build_kernel, dim3((unsigned)((threads + kBlock - 1) / kBlock) + (unsigned)bounds_blocks), dim3(kBlock), 0, c->stream,
-                       c->d_aux, n, c->m, n_rows, n_bands, n_pad, c->sigQ.p, c->sigT.p, c->sigP.p,
+                       c->d_aux, n, c->m, n_rows, n_bands, n_pad, c->sigQ.p, c->sigT.p, c->sigP.p, c->sigG.p,
                        bounds_blocks, c->d_cards, tau, c->mode == SELHIP_MODE_CB_SMH ? 1 : 0, row_map(c, rb, re), c->ecard.p, c->hi.p, c->pc.p,
-                       (c->p == 14 && c->group_stage2) ? c->csr_cnt.p : nullptr, (int)c->cand_begin);
+                       (c->p == 14 && c->group_stage2) ? c->csr_cnt.p : nullptr, (int)c->cand_begin,
+                       with_bounds ? c->seg_cnt.p : nullptr, with_bounds ? (int)c->seg_cnt.cap : 0);
     return hipGetLastError();
 }
 
@@ -391,8 +431,9 @@ hipError_t launch_stage1_sig(selhip_ctx* c, const StageIO& io, int n_rows, int n
         if (e != hipSuccess) return e;
         // the 16-bit matches were staged in the candidate list; survivors go to the survivor list as usual
         TimerScope t(c, T_VERIFY, io.st);
+        static_assert(1024 % kAppendSegs == 0, "verify16_kernel: the grid is a multiple of the segment count");
         hipLaunchKernelGGL(verify16_kernel, dim3(1024), dim3(kVerifyBlock), 0, io.st, c->d_aux, c->m, n_rows, n_bands, c->sigQ.p,
-                           io.cand, &io.pc->n_pre, io.cap, io.surv, io.cap, io.pc, c->verify_fb, io.row_cnt);
+                           io.cand, io.seg_cnt, io.cap, io.surv, io.cap, io.pc, c->verify_fb, io.row_cnt);
         return hipGetLastError();
     } else {
         TimerScope t(c, T_JOIN, io.st);
@@ -596,6 +637,7 @@ int enqueue_pass(selhip_ctx* c) {
         HIPCHK(&c->err, hipStreamWaitEvent(c->st_stage2, c->ev_start, 0));
         for (int k = 0; k < chunks; ++k) {
             StageIO io{c->st_stage1, c->cand.p + (size_t)k * slice, c->surv.p + (size_t)k * slice, slice, pc0 + 1 + k};
+            io.seg_cnt = c->seg_cnt.p + (size_t)(1 + k) * kAppendSegs * kSegStride;
             {
                 TimerScope t(c, T_STAGE1, io.st);
                 if (use_hash)     HIPCHK(&c->err, launch_stage1_hashjoin(c, io, c->n_rows, c->n_bands, (int)bnd[k], (int)bnd[k + 1]));
@@ -625,6 +667,7 @@ int enqueue_pass(selhip_ctx* c) {
 
     // ---- single chunk: everything in order on the context's stream (counter block 1)
     StageIO io{c->stream, c->cand.p, c->surv.p, (u64)c->surv.cap, pc0 + 1};
+    io.seg_cnt = c->seg_cnt.p + (size_t)kAppendSegs * kSegStride;
     // the survivors of the 16-bit signature path are the final list when smh_a is the only criterion: verify16_kernel
     // then tallies them per query row itself (no csr_count launch)
     const bool count_in_verify = crit == SELHIP_CRIT_SMH_A && use_sig && !use_hash && c->join_bits == 16 && c->p == 14 && c->group_stage2;
@@ -712,6 +755,7 @@ int ensure_scratch(selhip_ctx* c, size_t surv_cap, size_t res_cap) {
     HIPCHK(&c->err, c->ecard.ensure((size_t)c->n));
     HIPCHK(&c->err, c->hi.ensure((size_t)c->n));
     HIPCHK(&c->err, c->pc.ensure(kMaxChunks + 1));
+    HIPCHK(&c->err, c->seg_cnt.ensure((size_t)(kMaxChunks + 1) * kAppendSegs * kSegStride));
     if (!c->st_stage1) {
         HIPCHK(&c->err, hipStreamCreateWithFlags(&c->st_stage1, hipStreamNonBlocking));
         HIPCHK(&c->err, hipStreamCreateWithFlags(&c->st_stage2, hipStreamNonBlocking));
@@ -739,6 +783,7 @@ int ensure_scratch(selhip_ctx* c, size_t surv_cap, size_t res_cap) {
             HIPCHK(&c->err, c->sigQ.ensure((size_t)c->n * nb));
             HIPCHK(&c->err, c->sigT.ensure(n_pad * nb));
             HIPCHK(&c->err, c->sigP.ensure(n_pad * (size_t)((nb + 1) / 2)));
+            HIPCHK(&c->err, c->sigG.ensure((n_pad + 2) * (size_t)((nb + 1) / 2)));
         }
         if (hash) {
             const size_t total = (size_t)c->n * nb;
@@ -812,9 +857,9 @@ void selhip_ctx_destroy(selhip_ctx* c) {
     (void)hipStreamSynchronize(c->stream);
     drain_timers(c);
     c->own_hll.release(); c->own_aux.release(); c->own_cards.release();
-    c->ecard.release(); c->hi.release(); c->pc.release(); c->surv.release();
+    c->ecard.release(); c->hi.release(); c->pc.release(); c->seg_cnt.release(); c->surv.release();
     c->counts.release(); c->results.release(); c->self_pairs.release();
-    c->cand.release(); c->sigQ.release(); c->sigT.release(); c->sigP.release(); c->fin.release(); c->own_aux_hll.release();
+    c->cand.release(); c->sigQ.release(); c->sigT.release(); c->sigP.release(); c->sigG.release(); c->fin.release(); c->own_aux_hll.release();
     c->hj_keys_in.release(); c->hj_keys_out.release(); c->hj_vals_in.release(); c->hj_vals_out.release(); c->hj_tmp.release();
     c->csr_cnt.release(); c->csr_start.release(); c->grouped.release(); c->scan_tmp.release();
     if (c->h_pc) (void)hipHostFree(c->h_pc);
@@ -860,11 +905,17 @@ int selhip_ctx_set_param(selhip_ctx* c, const char* name, int value) {
     }
     if (!std::strcmp(name, "verify_fb")) { c->verify_fb = value != 0; return SELHIP_OK; }
     if (!std::strcmp(name, "join_wpb")) {
-        if (value != 1 && value != 4) { set_err(&c->err, "join_wpb must be 1 or 4"); return SELHIP_E_BADARG; }
+        if (value != 1 && value != 4 && value != 8) { set_err(&c->err, "join_wpb must be 1, 4 or 8"); return SELHIP_E_BADARG; }
         c->join_wpb = value;
         return SELHIP_OK;
     }
     if (!std::strcmp(name, "join_db")) { c->join_db = value != 0; return SELHIP_OK; }
+    if (!std::strcmp(name, "join_q")) { c->join_q = value != 0; return SELHIP_OK; }
+    if (!std::strcmp(name, "init_cap")) {
+        if (value < 0) { set_err(&c->err, "init_cap must be >= 0"); return SELHIP_E_BADARG; }
+        c->init_cap = value;
+        return SELHIP_OK;
+    }
     if (!std::strcmp(name, "join_bits")) {
         if (value != 16 && value != 32) { set_err(&c->err, "join_bits must be 16 or 32"); return SELHIP_E_BADARG; }
         c->join_bits = value;
@@ -1040,6 +1091,7 @@ int selhip_ctx_run_async(selhip_ctx* c, int mode, int algo, float tau_f, int n_r
         const double expect = (double)pair_bound(c->n, (int)row_begin, (int)row_end) / std::max(1, c->il_parts) * n_bands / 65536.0;
         surv_cap = std::max(surv_cap, (size_t)std::min(expect * 1.25 + 65536.0, (double)((size_t)1 << 26)));
     }
+    if (c->init_cap > 0) surv_cap = std::max<size_t>(c->surv.cap, (size_t)c->init_cap);       // test hook: start small, grow on overflow
     size_t res_cap = std::max<size_t>(c->results.cap, surv_cap);
     int rc = ensure_scratch(c, surv_cap, res_cap);
     if (rc) return rc;
@@ -1065,7 +1117,8 @@ int selhip_ctx_finish(selhip_ctx* c) {
         for (int k = 1; k <= chunks; ++k) {
             const PassCounters& q = c->h_pc[k];
             pc.n_survivors += q.n_survivors; pc.n_candidates += q.n_candidates; pc.n_aux_in += q.n_aux_in; pc.n_final += q.n_final;
-            const u64 worst = std::max(std::max(std::max(q.n_survivors, q.n_candidates), q.n_pre), c->criterion != SELHIP_CRIT_SMH_A ? q.n_final : 0);
+            // the 16-bit join's list is kAppendSegs equal slices: it overflows when its fullest slice does
+            const u64 worst = std::max(std::max(std::max(q.n_survivors, q.n_candidates), q.n_pre_segmax * (u64)kAppendSegs), c->criterion != SELHIP_CRIT_SMH_A ? q.n_final : 0);
             if (worst > slice) { surv_cap = std::max(surv_cap, (size_t)((worst + worst / 8 + 1024) * (u64)chunks)); grow = true; }
             if (q.n_aux_in > c->cand.cap) { c->pending = false; set_err(&c->err, "internal: enumerated pair list overflow"); return SELHIP_E_OVERFLOW; }
         }

@@ -1,24 +1,31 @@
 #!/usr/bin/env python3
-"""development sweep of the signature join (GPU box): selhip_ctx_set_param("join_bits" / "join_qt")"""
+"""development sweep of the signature join (GPU box): query side (SGPR / DPP), waves per block, groups per wave, tile height.
+   usage: join_sweep.py [workload ...]    prints one line per variant; every variant must report the same stats"""
 import sys
 from pathlib import Path
 ROOT = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT))
 import cuda_selection_criteria_amd as pkg
+
+VARIANTS = [  # (join_q, join_wpb, join_t, join_qt)
+    (0, 1, 1, 128), (1, 4, 1, 128), (1, 8, 1, 128), (1, 4, 2, 128), (1, 8, 2, 128),
+    (1, 4, 1, 64), (1, 8, 1, 64), (1, 4, 1, 96), (1, 4, 1, 256), (1, 8, 1, 256), (1, 4, 2, 256), (1, 4, 1, 384),
+]
 for wl in sys.argv[1:] or ("cfg3", "cfg4"):
     cfg = pkg.SYNTH_CONFIGS[wl]
     hll, aux, cards, _, _ = pkg.synth_device(cfg)
     r, b = pkg.banding(cfg.m, cfg.tau)
     sel = pkg.Selector(0); sel.attach(hll, aux, cards)
-    for bits, db in ((16, 4), (16, 1)):
-        sel.set_param("join_bits", bits); sel.set_param("join_wpb", db)
-        for qt in (64, 96, 128):
-            sel.set_param("join_qt", qt)
-            for _ in range(2): sel.run(cfg.tau, pkg.MODE_SMH, r, b, algo=pkg.ALGO_SIG, fetch=False)
-            st = sel.stats()
-            sel.timing(True)
-            for _ in range(6): sel.run(cfg.tau, pkg.MODE_SMH, r, b, algo=pkg.ALGO_SIG, fetch=False)
-            print(wl, "bits=%d db=%d qt=%d" % (bits, db, qt), "sigbuild=%.1f join=%.1f verify=%.1f total=%.1f us" % tuple(sel.kernel_ms(k) * 1e3 for k in ("sigbuild", "join", "verify", "total")), "stats", st, flush=True)
-            sel.timing(False)
+    ref = None
+    for q, wpb, t, qt in VARIANTS:
+        sel.set_param("join_q", q); sel.set_param("join_wpb", wpb); sel.set_param("join_t", t); sel.set_param("join_qt", qt)
+        for _ in range(2): sel.run(cfg.tau, pkg.MODE_SMH, r, b, algo=pkg.ALGO_SIG, fetch=False)
+        st = sel.stats()
+        if ref is None: ref = st
+        sel.timing(True)
+        for _ in range(6): sel.run(cfg.tau, pkg.MODE_SMH, r, b, algo=pkg.ALGO_SIG, fetch=False)
+        print(wl, "q=%d wpb=%d t=%d qt=%d" % (q, wpb, t, qt), "sigbuild=%.1f join=%.1f verify=%.1f total=%.1f us" % tuple(sel.kernel_ms(k) * 1e3 for k in ("sigbuild", "join", "verify", "total")),
+              "OK" if st == ref else "MISMATCH %s vs %s" % (st, ref), flush=True)
+        sel.timing(False)
     sel.close()
     del hll, aux, cards

@@ -258,9 +258,13 @@ def test_join_and_histogram_variants(oracle):
         with Selector(0) as sel:
             sel.upload(hll, aux, cards)
             cand = None
-            for bits, db, fb in ((16, 1, 0), (16, 0, 0), (32, 0, 0), (16, 1, 1), (16, 0, 1)):
+            # (bits, double-buffered DPP batches, forced verify fallback, query side 1 = LDS tile / 0 = DPP, waves per block,
+            #  candidate groups per wave, tile height)
+            for bits, db, fb, q, wpb, t, qt in ((16, 1, 0, 1, 4, 1, 128), (16, 1, 0, 1, 8, 2, 64), (16, 1, 0, 1, 4, 2, 16), (16, 1, 0, 1, 8, 1, 256),
+                                                (16, 1, 0, 0, 1, 1, 128), (16, 0, 0, 0, 4, 1, 96), (32, 0, 0, 0, 1, 1, 128),
+                                                (16, 1, 1, 1, 4, 1, 128), (16, 0, 1, 0, 4, 1, 128)):
                 sel.set_param("join_bits", bits); sel.set_param("join_db", db); sel.set_param("verify_fb", fb)
-                sel.set_param("join_wpb", 4 if fb else 1)
+                sel.set_param("join_q", q); sel.set_param("join_wpb", wpb); sel.set_param("join_t", t); sel.set_param("join_qt", qt)
                 assert_same_pairs(sel.run(tau, MODE_CB_SMH, r, b, algo=ALGO_SIG), want)
                 s = sel.stats()
                 assert s["evaluated"] == st["evaluated"] and s["survivors"] == st["survivors"]
@@ -269,13 +273,39 @@ def test_join_and_histogram_variants(oracle):
                 assert s["survivors"] == st_all["survivors"]
                 cand = s["candidates"] if cand is None else cand
                 assert s["candidates"] == cand          # the 32-bit candidate set is the same whichever join produced it
-            sel.set_param("join_bits", 16); sel.set_param("join_db", 1); sel.set_param("verify_fb", 0); sel.set_param("join_wpb", 1)
+            sel.set_param("join_bits", 16); sel.set_param("join_db", 1); sel.set_param("verify_fb", 0); sel.set_param("join_wpb", 4)
+            sel.set_param("join_q", 1); sel.set_param("join_t", 1); sel.set_param("join_qt", 128)
             for run, blocks in ((1, 8), (3, 64), (8, 2048), (1024, 16384), (1, 16384)):
                 sel.set_param("hist_run", run); sel.set_param("hist_blocks", blocks)
                 assert_same_pairs(sel.run(tau, MODE_CB_SMH, r, b), want)
-            for bad in (("join_bits", 24), ("join_wpb", 2), ("hist_blocks", 12), ("hist_run", 0), ("no_such_param", 1)):
+            for bad in (("join_bits", 24), ("join_wpb", 2), ("join_t", 3), ("init_cap", -1), ("hist_blocks", 12), ("hist_run", 0), ("no_such_param", 1)):
                 with pytest.raises(pkg.SelhipError):
                     sel.set_param(*bad)
+
+
+@pytest.mark.parametrize("algo", [ALGO_SIG, ALGO_STREAM, ALGO_HASHJOIN])
+@pytest.mark.parametrize("grouping", [True, False])
+def test_list_overflow_grows_and_repeats(oracle, algo, grouping):
+    """the candidate / survivor / result lists start far too small ("init_cap" test hook): the pass must notice from its exact
+    counters, grow the lists and repeat -- never read or write past a list (the per-row tally of verify16_kernel
+    used to count clipped survivors, so the row-grouped copy was written out of bounds) -- and give the oracle's pairs"""
+    cfg = make_golden.GOLDEN_SYNTH["synth_flat_n300_m512"]
+    hll, aux, cards, _, _ = sorted_set(cfg, oracle)
+    r, b = pkg.banding(cfg.m, 0.5)
+    want, st = oracle.select(hll, aux, cards, 0.5, r, b, use_cb=False)
+    assert st["survivors"] > 600
+    with Selector(0) as sel:
+        sel.set_param("init_cap", 128)                       # 2 records per append segment of the join
+        sel.set_stage2_grouping(grouping)
+        sel.upload(hll, aux, cards)
+        got = sel.run(0.5, MODE_SMH, r, b, algo=algo)
+        assert sel.last_attempts() >= 2
+        assert_same_pairs(got, want)
+        s = sel.stats()
+        assert s["survivors"] == st["survivors"] and s["evaluated"] == st["evaluated"]
+        got = sel.run(0.5, MODE_SMH, r, b, algo=algo)       # the grown lists are kept: one attempt now
+        assert sel.last_attempts() == 1
+        assert_same_pairs(got, want)
 
 
 def test_edge_cases(oracle):
