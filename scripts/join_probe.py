@@ -10,7 +10,7 @@ cfg = pkg.SYNTH_CONFIGS[wl]
 hll, aux, cards, _, _ = pkg.synth_device(cfg)
 r, b = pkg.banding(cfg.m, cfg.tau)
 sel = pkg.Selector(0); sel.attach(hll, aux, cards)
-sel.set_param("join_q", q); sel.set_param("join_wpb", wpb); sel.set_param("join_t", t); sel.set_param("join_qt", qt); sel.set_param("join_dbg", dbg)
+sel.set_param("join_q", q); sel.set_param("join_wpb", wpb); sel.set_param("join_qt", qt); sel.set_param("join_dbg", dbg)
 for _ in range(3): sel.run(cfg.tau, pkg.MODE_SMH, r, b, algo=pkg.ALGO_SIG, fetch=False)
 print(sel.stats())
 sel.close()

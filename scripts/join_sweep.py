@@ -18,7 +18,7 @@ for wl in sys.argv[1:] or ("cfg3", "cfg4"):
     sel = pkg.Selector(0); sel.attach(hll, aux, cards)
     ref = None
     for q, wpb, t, qt in VARIANTS:
-        sel.set_param("join_q", q); sel.set_param("join_wpb", wpb); sel.set_param("join_t", t); sel.set_param("join_qt", qt)
+        sel.set_param("join_q", q); sel.set_param("join_wpb", wpb); sel.set_param("join_qt", qt)
         for _ in range(2): sel.run(cfg.tau, pkg.MODE_SMH, r, b, algo=pkg.ALGO_SIG, fetch=False)
         st = sel.stats()
         if ref is None: ref = st

@@ -259,12 +259,12 @@ def test_join_and_histogram_variants(oracle):
             sel.upload(hll, aux, cards)
             cand = None
             # (bits, double-buffered DPP batches, forced verify fallback, query side 1 = LDS tile / 0 = DPP, waves per block,
-            #  candidate groups per wave, tile height)
-            for bits, db, fb, q, wpb, t, qt in ((16, 1, 0, 1, 4, 1, 128), (16, 1, 0, 1, 8, 2, 64), (16, 1, 0, 1, 4, 2, 16), (16, 1, 0, 1, 8, 1, 256),
-                                                (16, 1, 0, 0, 1, 1, 128), (16, 0, 0, 0, 4, 1, 96), (32, 0, 0, 0, 1, 1, 128),
-                                                (16, 1, 1, 1, 4, 1, 128), (16, 0, 1, 0, 4, 1, 128)):
+            #  tile height)
+            for bits, db, fb, q, wpb, qt in ((16, 1, 0, 1, 4, 64), (16, 1, 0, 1, 8, 128), (16, 1, 0, 1, 4, 16), (16, 1, 0, 1, 8, 256),
+                                             (16, 1, 0, 0, 1, 128), (16, 0, 0, 0, 4, 96), (32, 0, 0, 0, 1, 128),
+                                             (16, 1, 1, 1, 4, 64), (16, 0, 1, 0, 4, 128)):
                 sel.set_param("join_bits", bits); sel.set_param("join_db", db); sel.set_param("verify_fb", fb)
-                sel.set_param("join_q", q); sel.set_param("join_wpb", wpb); sel.set_param("join_t", t); sel.set_param("join_qt", qt)
+                sel.set_param("join_q", q); sel.set_param("join_wpb", wpb); sel.set_param("join_qt", qt)
                 assert_same_pairs(sel.run(tau, MODE_CB_SMH, r, b, algo=ALGO_SIG), want)
                 s = sel.stats()
                 assert s["evaluated"] == st["evaluated"] and s["survivors"] == st["survivors"]
@@ -274,11 +274,11 @@ def test_join_and_histogram_variants(oracle):
                 cand = s["candidates"] if cand is None else cand
                 assert s["candidates"] == cand          # the 32-bit candidate set is the same whichever join produced it
             sel.set_param("join_bits", 16); sel.set_param("join_db", 1); sel.set_param("verify_fb", 0); sel.set_param("join_wpb", 4)
-            sel.set_param("join_q", 1); sel.set_param("join_t", 1); sel.set_param("join_qt", 128)
+            sel.set_param("join_q", 1); sel.set_param("join_qt", 64)
             for run, blocks in ((1, 8), (3, 64), (8, 2048), (1024, 16384), (1, 16384)):
                 sel.set_param("hist_run", run); sel.set_param("hist_blocks", blocks)
                 assert_same_pairs(sel.run(tau, MODE_CB_SMH, r, b), want)
-            for bad in (("join_bits", 24), ("join_wpb", 2), ("join_t", 3), ("init_cap", -1), ("hist_blocks", 12), ("hist_run", 0), ("no_such_param", 1)):
+            for bad in (("join_bits", 24), ("join_wpb", 2), ("init_cap", -1), ("hist_blocks", 12), ("hist_run", 0), ("no_such_param", 1)):
                 with pytest.raises(pkg.SelhipError):
                     sel.set_param(*bad)
 
