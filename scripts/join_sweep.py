@@ -7,9 +7,8 @@ ROOT = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT))
 import cuda_selection_criteria_amd as pkg
 
-VARIANTS = [  # (join_q, join_wpb, join_t, join_qt)
-    (0, 1, 1, 128), (1, 4, 1, 128), (1, 8, 1, 128), (1, 4, 2, 128), (1, 8, 2, 128),
-    (1, 4, 1, 64), (1, 8, 1, 64), (1, 4, 1, 96), (1, 4, 1, 256), (1, 8, 1, 256), (1, 4, 2, 256), (1, 4, 1, 384),
+VARIANTS = [  # (join_q: 1 = LDS query tile / 0 = DPP broadcast, join_wpb, join_qt)
+    (0, 1, 128), (0, 4, 128), (1, 4, 64), (1, 8, 64), (1, 4, 96), (1, 4, 128), (1, 8, 128), (1, 4, 256), (1, 8, 256),
 ]
 for wl in sys.argv[1:] or ("cfg3", "cfg4"):
     cfg = pkg.SYNTH_CONFIGS[wl]
@@ -17,14 +16,14 @@ for wl in sys.argv[1:] or ("cfg3", "cfg4"):
     r, b = pkg.banding(cfg.m, cfg.tau)
     sel = pkg.Selector(0); sel.attach(hll, aux, cards)
     ref = None
-    for q, wpb, t, qt in VARIANTS:
+    for q, wpb, qt in VARIANTS:
         sel.set_param("join_q", q); sel.set_param("join_wpb", wpb); sel.set_param("join_qt", qt)
         for _ in range(2): sel.run(cfg.tau, pkg.MODE_SMH, r, b, algo=pkg.ALGO_SIG, fetch=False)
         st = sel.stats()
         if ref is None: ref = st
         sel.timing(True)
         for _ in range(6): sel.run(cfg.tau, pkg.MODE_SMH, r, b, algo=pkg.ALGO_SIG, fetch=False)
-        print(wl, "q=%d wpb=%d t=%d qt=%d" % (q, wpb, t, qt), "sigbuild=%.1f join=%.1f verify=%.1f total=%.1f us" % tuple(sel.kernel_ms(k) * 1e3 for k in ("sigbuild", "join", "verify", "total")),
+        print(wl, "q=%d wpb=%d qt=%d" % (q, wpb, qt), "sigbuild=%.1f join=%.1f verify=%.1f total=%.1f us" % tuple(sel.kernel_ms(k) * 1e3 for k in ("sigbuild", "join", "verify", "total")),
               "OK" if st == ref else "MISMATCH %s vs %s" % (st, ref), flush=True)
         sel.timing(False)
     sel.close()
