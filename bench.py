@@ -6,20 +6,35 @@ i<k goes through the smh_a band predicate, survivors through the HLL-14 union es
 test) over one synthetic sketch set that is already resident in HBM, ending with the selected-pair
 list of all ranks gathered on every rank (RCCL all_gather over xGMI when --gpus > 1).
 
-Workload at 1 GPU: BASELINE.json configs[2] = 10 000 synthetic genomes, smh_a m=512, tau=0.8 -- the
-configuration the north_star target (>= 1e10 m=512 bucket-pair-comparisons/s, >= 40 % of the HBM
-roofline) is quoted on.  At N GPUs the genome count is scaled by sqrt(N) (per-GPU pair count fixed:
-weak scaling) and the pair space is sharded by query rows, equal pairs per rank; every rank holds a
-full replica of the sketches; rows are dealt to ranks in interleaved blocks of 128.
+Workloads
+  default, N = 1        BASELINE.json configs[2]: 10 000 synthetic genomes, smh_a m=512, tau=0.8.
+  default, N > 1        the same configuration weak-scaled: genome count x sqrt(N), so that every GPU keeps
+                        configs[2]'s pair count ("scaling": "weak").
+  --workload cfg4 --scaling strong
+                        BASELINE.json configs[3]: 50 000 genomes, m=512, the SAME 1.25e9 pairs sharded over
+                        the N GPUs ("scaling": "strong") -- the second scaling line.
+  --workload cfg5 [--scaling strong]   configs[4]: 100 000 genomes, hll_a(p=8) prefilter + smh_a m=1024.
+The pair space is sharded by query rows: interleaved blocks of 128 rows, block b on rank b mod N; every rank holds a
+full replica of the sketches.
 
-Prints ONE JSON line on rank 0 (contract in the task statement) with the extra objects `roofline`
-(dominant kernel = stage 1, HIP-event timed inside the timed region) and `cpu_baseline` (the oracle,
-an OpenMP port of selection.cpp's loop, on a bounded sample; N=1 only).
+`python bench.py --gpus N` with N > 1 and no torch.distributed environment starts its own ranks: it runs
+`python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py <same arguments>` as a CHILD process,
+before anything in this process has touched the GPU, and exits with the child's code.
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with the extra objects
+  roofline          the binding resource of the dominant kernel (vector-instruction issue for the signature join), frac <= 1;
+  hbm_algorithmic   SURVEY.md 8(d)'s nominal 8*m bytes per pair-comparison against the HBM peak (NOT a bound of this design);
+  stage2_roofline   LDS issue of the union-histogram kernel;
+  stream_kernel     the literal north_star kernel (query tile in LDS, candidates streamed from HBM) on the same inputs;
+  harder_workload   the same configuration with 25 % degenerate genomes (1.4 % of all pairs pass a band);
+  cpu_baseline      the oracle (OpenMP port of selection.cpp's loop) on a bounded sample, all cores; cpu_baseline_8t: 8 threads.
 """
 import argparse
 import json
 import math
 import os
+import socket
+import subprocess
 import sys
 import time
 from pathlib import Path
@@ -27,7 +42,15 @@ from pathlib import Path
 ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
-HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip-level parameters)
+# ---- hardware constants (every one traceable to a file under profiles/ or to the guide) -----------------------------
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak (MI355X_MICROARCH.md, chip-level parameters)
+N_SIMD = 256 * 4               # 256 CUs x 4 SIMDs
+SHADER_HZ = 2.4e9              # profiles/r02_valu_rate.txt: s_memtime tick rate 2407 MHz, rates quoted at 2400 MHz
+# profiles/r02_valu_rate.txt (scripts/microbench/valu_rate.hip), cycles per wave64 instruction per SIMD at >= 4 waves/SIMD:
+CYC_VALU_PLAIN = 2.07          # VGPR-only VOP2 (v_xor_b32, v_and_b32, v_add_u32, v_min_u16, v_fma_f32 ...) -- two waves co-issue
+CYC_VALU_FULL = 4.07           # anything with DPP / SDWA / an SGPR operand / three sources (VOP3) / packed math (VOP3P)
+CYC_DS_2DWORD = 4.0            # MI355X_MICROARCH.md LDS table: a DS op moving 2 dwords per lane (ds_add_u32, ds_write_b32) = 4 cycles/CU
+IL_BLOCK = 128                 # rows per interleave block of the multi-GPU partition
 
 
 def parse():
@@ -36,39 +59,66 @@ def parse():
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="cfg3", help="key of cuda_selection_criteria_amd.synth.SYNTH_CONFIGS")
-    ap.add_argument("--genomes", type=int, default=0, help="override the genome count (0 = config value, scaled by sqrt(gpus))")
+    ap.add_argument("--genomes", type=int, default=0, help="override the genome count (0 = config value; weak scaling multiplies it by sqrt(gpus))")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
     ap.add_argument("--mode", choices=["smh_a", "CB+smh_a"], default="smh_a")
     ap.add_argument("--algo", choices=["auto", "stream", "sig", "hashjoin"], default="auto",
                     help="hashjoin = sub-quadratic sort-based candidate generation: NOT the brute-force pair-comparison metric")
+    ap.add_argument("--join-q", type=int, default=-1, help="signature join query side: 1 LDS tile (default), 0 DPP broadcast")
+    ap.add_argument("--hard", action="store_true", help="run the harder variant of the workload (25 %% degenerate genomes) as the main line")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip stream_kernel / harder_workload (profiling runs)")
     ap.add_argument("--no-grouping", action="store_true", help="stage 2 without bucketing the survivors by query row")
     ap.add_argument("--pipeline", type=int, default=-1, help="-1 auto, 0 off, 2..8 row chunks (stage 1 of chunk c+1 overlaps stage 2 of chunk c)")
     ap.add_argument("--pcie", action="store_true", help="also time a PCIe-inclusive pass (host buffers -> upload -> run)")
     ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed and run the collectives even with one rank (RCCL smoke test)")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
                     help="gloo = rehearsal of the multi-rank logic on a box with fewer GPUs than ranks (records staged through the host)")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the baseline sample")
+    ap.add_argument("--cpu-seconds", type=float, default=10.0, help="target CPU time of each baseline sample")
     return ap.parse_args()
+
+
+def spawn_ranks(args):
+    """--gpus N > 1 without a torch.distributed environment: start the N ranks as a child process tree.  Nothing in THIS
+    process has initialised the GPU (no torch import yet), and the child is a fresh interpreter -- no exec of a GPU process."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), str(Path(__file__).resolve())] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "8")
+    return subprocess.run(cmd, env=env).returncode
+
+
+def join_issue_model(n_bands, join_q):
+    """VALU wave-instructions of the signature join per (query row x 64 candidates), split by issue cost -- counted from the ISA
+    (csrc/kernel_sigjoin.cuh: per packed dword one xor and one v_pk_min_u16; per row 3 v_pk_min_u16 + v_min_u32_sdwa + v_cmp)."""
+    nd = n_bands // 2
+    if join_q:
+        return {"plain": nd, "full": nd + 5}        # LDS form: the xor is a VGPR-only VOP2
+    return {"plain": 0, "full": 2 * nd + 5}         # DPP form: v_xor_b32_dpp is a full-cost instruction
 
 
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
+        sys.exit(spawn_ranks(args))
+
     import numpy as np
     import torch
     import torch.distributed as dist
 
     import cuda_selection_criteria_amd as pkg
-    from cuda_selection_criteria_amd import _lib
+    from cuda_selection_criteria_amd import distributed as D
     from cuda_selection_criteria_amd.selection import PAIR_DTYPE
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
-        args.gpus = world
+    args.gpus = world
     if not torch.cuda.is_available():
         sys.exit("bench.py needs an MI355X: the product path has no CPU fallback")
     local_rank = local_rank % torch.cuda.device_count()
@@ -101,11 +151,15 @@ def main():
 
     # ---- inputs: generated in HBM, sorted into rank order (identical replica on every rank) --------------
     hll_t, aux_t, cards_t, _, aux_hll_t = pkg.synth_device(cfg, device=local_rank)
+    n_degenerate = pkg.harden(aux_t) if args.hard else 0
     cards = cards_t.cpu().numpy()
     sel = pkg.Selector(local_rank)
     sel.attach(hll_t, aux_t, cards_t)
     sel.set_pipeline(args.pipeline)
-    IL_BLOCK = 128
+    join_q = 1
+    if args.join_q >= 0:
+        join_q = int(args.join_q != 0)
+        sel.set_param("join_q", join_q)
     if world > 1:
         # shard the pair space by interleaved blocks of query rows: rank r owns the blocks b with b % world == r, i.e. an
         # equal share of the pairs AND of the survivors (stage 2) -- a contiguous equal-pair cut would leave the last rank
@@ -116,28 +170,7 @@ def main():
     if two_stage:
         sel.attach_aux_hll(aux_hll_t, cfg.p_aux)
         sel.set_criterion(pkg.CRIT_HLL_A_SMH_A)
-
-    # ---- shard the pair space by query rows: equal pair counts per rank ------------------------------------
-    bounds = np.zeros(world + 1, dtype=np.int64)
-    hi = None
-    if mode == pkg.MODE_CB_SMH:
-        e = cards.astype(np.uint64)          # truncation like (size_t)card
-        tau64 = float(np.float32(cfg.tau))
-        hi = np.empty(n_genomes, dtype=np.int32)
-        for i in range(n_genomes):           # monotone: binary search per row (host plan, outside the timed region)
-            lo_, hi_ = i, n_genomes - 1
-            while lo_ < hi_:
-                mid = (lo_ + hi_ + 1) // 2
-                ok = e[mid] == 0 or (float(e[i]) / float(e[mid]) >= tau64)
-                if ok:
-                    lo_ = mid
-                else:
-                    hi_ = mid - 1
-            hi[i] = lo_
-    z0 = int(np.argmax(cards >= 1.0)) if (cards >= 1.0).any() else n_genomes
-    rc = pkg.host_lib().selhost_shard_rows(n_genomes, hi.ctypes.data if hi is not None else None, z0, world, bounds.ctypes.data)
-    assert rc == 0
-    row_lo, row_hi = (0, n_genomes) if world > 1 else (int(bounds[rank]), int(bounds[rank + 1]))
+    row_lo, row_hi = 0, n_genomes                  # the interleave (not a row range) partitions the rows
 
     # gather: ONE all_gather per step of a fixed-capacity record buffer whose record 0 carries the count.
     # The capacity is sized from the first (untimed) step: 1.25 x the largest per-rank count, so the timed loop
@@ -213,7 +246,7 @@ def main():
             dist.barrier()
             torch.cuda.synchronize(dev)
 
-    for _ in range(args.warmup):
+    for _ in range(max(1, args.warmup)):
         step()
     # HIP events over the timed region on the dominant stage-1 kernel only (timing level 2): an event pair costs ~10 us of
     # stream time, so the other kernels' figures are collected in extra passes after the timed region
@@ -221,7 +254,7 @@ def main():
     sync_all()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        n_sel_local = step()
+        step()
     sync_all()
     dt = time.perf_counter() - t0
     st = sel.stats()
@@ -229,7 +262,6 @@ def main():
     dom_key = "join" if used_sig else "stage1"
     dom_pass_ms = sel.kernel_ms(dom_key)                         # all launches of one pass (a pipelined pass: one per row chunk)
     dom_launches = max(1.0, sel.kernel_launches(dom_key))
-    stage1_ms = dom_pass_ms
     sel.timing(1)                                                # outside the timed region: every kernel scope, a few passes
     for _ in range(5):
         step()
@@ -238,14 +270,13 @@ def main():
     sel.timing(0)
 
     t_max = torch.tensor([dt], dtype=torch.float64, device=cdev)
-    totals = torch.tensor([st["evaluated"], st["survivors"], st["selected"]], dtype=torch.int64, device=cdev)
-    s1 = torch.tensor([stage1_ms], dtype=torch.float64, device=cdev)
+    totals = torch.tensor([st["evaluated"], st["survivors"], st["selected"], 1], dtype=torch.int64, device=cdev)
     if dist_on:
         dist.all_reduce(t_max, op=dist.ReduceOp.MAX)
         dist.all_reduce(totals, op=dist.ReduceOp.SUM)
-        dist.all_reduce(s1, op=dist.ReduceOp.MAX)
     dt = float(t_max.item())
     pairs_per_step = int(totals[0].item())
+    n_ranks_seen = int(totals[3].item())
     value = pairs_per_step * args.steps / dt
 
     # ---- result check outside the timed region: the gathered list holds every rank's records -------------------
@@ -259,72 +290,97 @@ def main():
         assert len(np.unique(key)) == len(key), "duplicate pairs across shards"
         for r in range(world):                        # every record sits in a row block owned by the rank that sent it
             ii = rec[r, 1:1 + int(cts[r])].reshape(-1).view(PAIR_DTYPE)["i"]
-            assert (world == 1) or (((ii // IL_BLOCK) % world) == r).all()
+            assert (world == 1) or (D.interleave_owner(ii, IL_BLOCK, world) == r).all()
+        if mode == pkg.MODE_SMH:                      # the shards tile the whole triangle
+            assert pairs_per_step == n_genomes * (n_genomes - 1) // 2, (pairs_per_step, n_genomes)
 
     out = None
     if rank == 0:
         pairs_rank0 = st["evaluated"]
-        alg_bytes = pairs_rank0 * 8 * cfg.m                     # 8*m bytes per pair-comparison
         launches = dom_launches
         dom_ms = dom_pass_ms / launches                          # average launch duration, measured inside the timed region
-        alg_bytes = alg_bytes / launches                         # algorithmic bytes of one launch
-        dom_name = (f"sig16_join_kernel<{n_bands // 2}> ({n_bands} bands, 16-bit signatures two per dword)" if args.algo != "hashjoin" else "sort-based join") if used_sig else "smh_stream_kernel"
-        achieved = alg_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else None
-        traffic = None
+        alg_bytes = pairs_rank0 * 8 * cfg.m / launches           # 8*m bytes per pair-comparison, per launch
+        if used_sig:
+            dom_name = (f"sigl_join_kernel<{n_bands // 2}> (query tile in LDS)" if join_q else f"sig16_join_kernel<{n_bands // 2}> (DPP broadcast)") \
+                if args.algo != "hashjoin" else "sort-based join"
+        else:
+            dom_name = "smh_stream_kernel"
+        traffic, traffic_src = None, None
         tfile = ROOT / "profiles" / "stage1_traffic.json"
         if tfile.exists():
             try:
-                traffic = json.loads(tfile.read_text()).get(f"{args.workload}:{'sig' if used_sig else 'stream'}")
+                tj = json.loads(tfile.read_text())
+                traffic = tj.get(f"{args.workload}:{'sig' if used_sig else 'stream'}")
                 traffic = traffic / launches if traffic else traffic        # stored per step
+                traffic_src = tj.get("source", "profiles/stage1_traffic.json") + " (rocprofv3 --pmc pass of this command on an earlier run; NOT measured by this run)"
             except Exception:
                 traffic = None
         hist_ms = detail_ms["hist"]
         surv0 = st["survivors"]
         kernels = {k: v for k, v in detail_ms.items() if v > 0}
         kernels[dom_key + "_in_timed_region"] = dom_pass_ms
+        achieved_hbm = alg_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else None
         out = {
             "metric": "sketch pair-comparisons/sec (N genomes x m buckets)",
             "value": value, "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": args.scaling,
             "vs_baseline": None, "dtype": "u64", "data": "synthetic",
-            "config": {"workload": f"{cfg.name}; mode {args.mode}; bands {n_bands} x {n_rows} rows; "
+            "config": {"workload": f"{cfg.name}{' +25% degenerate genomes' if args.hard else ''}; mode {args.mode}; bands {n_bands} x {n_rows} rows; "
                                    f"pair space sharded by query rows over {world} GPU(s), selected pairs all_gathered",
                        "n_genomes": n_genomes, "m": cfg.m, "tau": cfg.tau,
                        "algo": "hashjoin (pairs are NOT compared one by one: equivalent pairs/s)" if args.algo == "hashjoin" else ("sig" if used_sig else "stream"),
                        "criterion": "hll_a+smh_a" if two_stage else "smh_a",
                        "pairs_per_step": pairs_per_step, "selected_pairs": int(totals[2].item()),
-                       "stage1_survivors": int(totals[1].item())},
-            "bucket_pair_comparisons_per_s": value * cfg.m,
-            "roofline": {"bound": "hbm", "kernel": dom_name + " (stage 1, all-pairs)", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
-                         "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": dom_ms, "launches_per_step": launches,
-                         "note": "algorithmic bytes = 8*m per pair-comparison (SURVEY.md 8d: one candidate sketch streamed per "
-                                 "pair, query on chip). Both stage-1 kernels reuse every byte they load across a tile of "
-                                 "queries, so the algorithmic rate exceeds the HBM peak; `traffic` = measured HBM bytes/launch "
-                                 "(rocprofv3 FETCH_SIZE/WRITE_SIZE, profiles/). The signature join is bound by VALU issue "
-                                 "(1.5 VALU per band and 64 pairs), see `valu`."},
-            "stage2_roofline": {"bound": "lds", "kernel": "hll_union_hist_runs_kernel",
-                                "achieved": (surv0 * 256 / (hist_ms * 1e-3)) if hist_ms > 0 else None, "peak": 256 * 2.4e9 / 4.5,
-                                "unit": "ds_add_u32 wave-instructions/s",
-                                "frac": (surv0 * 256 / (hist_ms * 1e-3)) / (256 * 2.4e9 / 4.5) if hist_ms > 0 else None,
-                                "ms_per_step": hist_ms, "row_bytes_per_s": (surv0 * 32768 / (hist_ms * 1e-3)) if hist_ms > 0 else None,
-                                "note": "one conflict-free ds_add_u32 per 64 register pairs, 256 per surviving pair; peak = 256 CUs x one "
-                                        "such instruction per ~4.5 cycles (scripts/microbench/lds_atomic_rate.hip on this part); "
-                                        "row_bytes_per_s = the 2 x 16 KiB of HLL registers per pair, served mostly by L2/MALL"},
+                       "stage1_survivors": int(totals[1].item()), "n_ranks_seen": n_ranks_seen},
+            "bucket_pair_comparisons_per_s_nominal": value * cfg.m,
             "kernel_ms": kernels,
         }
-        if used_sig and dom_ms > 0:
-            groups = (n_genomes + 63) // 64
-            wave_queries = pairs_rank0 / 64.0                    # one query against one 64-candidate group
-            valu = wave_queries * n_bands * 1.0                 # v_xor_b32_dpp + v_pk_min_u16 per TWO bands
-            dom_ms = dom_pass_ms
-            out["roofline"]["valu"] = {"achieved_wave_instr_per_s": valu / (dom_ms * 1e-3), "peak_wave_instr_per_s": 256 * 4 * 2.4e9 / 4,
-                                       "frac": valu / (dom_ms * 1e-3) / (256 * 4 * 2.4e9 / 4),
-                                       "note": "peak = 1024 SIMDs x 2.4 GHz / 4 cycles per wave64 VALU instruction"}
+        if used_sig and args.algo != "hashjoin" and dom_ms > 0:
+            out["bucket_pair_comparisons_note"] = ("nominal = pairs/s x m: the signature join decides every pair from n_bands 16-bit band "
+                                                   "signatures, it does not execute m bucket compares per pair (the stream kernel's figure in "
+                                                   "`stream_kernel` is the executed one)")
+            row_waves = pairs_rank0 / 64.0                     # one query row against one group of 64 candidates
+            mdl = join_issue_model(n_bands, join_q)
+            n_instr = mdl["plain"] + mdl["full"]
+            cyc_mix = (mdl["plain"] * CYC_VALU_PLAIN + mdl["full"] * CYC_VALU_FULL) / n_instr
+            peak = N_SIMD * SHADER_HZ / cyc_mix
+            achieved = row_waves * n_instr / (dom_pass_ms * 1e-3)
+            out["roofline"] = {
+                "bound": "valu_issue", "kernel": dom_name + " (stage 1, all-pairs)", "achieved": achieved / 1e9, "peak": peak / 1e9,
+                "unit": "G wave-instr/s", "frac": achieved / peak, "traffic": traffic, "traffic_source": traffic_src,
+                "avg_launch_ms": dom_ms, "launches_per_step": launches,
+                "instr_per_row_wave": mdl, "cycles_per_instr_at_peak": cyc_mix,
+                "peak_derivation": f"{N_SIMD} SIMDs x {SHADER_HZ / 1e9} GHz / mix-weighted issue cost; profiles/r02_valu_rate.txt: "
+                                   f"VGPR-only VOP2 {CYC_VALU_PLAIN} cycles (two waves co-issue), every DPP/SDWA/SGPR-operand/VOP3/packed instruction "
+                                   f"{CYC_VALU_FULL} cycles; the same file's 'mix: v_xor_b32 / v_pk_min_u16' rows (3.75-3.93 cycles per instruction) show "
+                                   "that a plain instruction only pairs with another plain one, so this peak is not reachable with a packed min in the loop",
+                "note": "achieved = model count of VALU wave-instructions (ISA, csrc/kernel_sigjoin.cuh) / join time inside the timed region; "
+                        "PMC SQ_INSTS_VALU of the same kernel: profiles/"}
+        else:
+            out["roofline"] = {"bound": "salu_issue" if not used_sig else "n/a", "kernel": dom_name, "avg_launch_ms": dom_ms,
+                               "launches_per_step": launches, "traffic": traffic, "traffic_source": traffic_src,
+                               "achieved": None, "peak": None, "unit": "G instr/s", "frac": None}
+        out["hbm_algorithmic"] = {"bytes_per_pair": 8 * cfg.m, "achieved_GBs": achieved_hbm, "peak_GBs": HBM_PEAK_GBS,
+                                  "ratio": (achieved_hbm / HBM_PEAK_GBS) if achieved_hbm else None,
+                                  "note": "SURVEY.md 8(d) nominal: one candidate sketch streamed per pair-comparison.  NOT a bound of this design: "
+                                          "both stage-1 kernels reuse every byte they load against a tile of queries, so the ratio exceeds 1; "
+                                          "measured HBM traffic per launch is `roofline.traffic`"}
+        if hist_ms > 0:
+            ds_rate = surv0 * 256 / (hist_ms * 1e-3)
+            ds_peak = 256 * SHADER_HZ / CYC_DS_2DWORD
+            out["stage2_roofline"] = {"bound": "lds_issue", "kernel": "hll_union_hist_runs_kernel", "achieved": ds_rate / 1e9, "peak": ds_peak / 1e9,
+                                      "unit": "G ds_add_u32 wave-instr/s", "frac": ds_rate / ds_peak, "ms_per_step": hist_ms,
+                                      "row_bytes_per_s": surv0 * 32768 / (hist_ms * 1e-3),
+                                      "note": "one conflict-free ds_add_u32 per 64 register pairs, 256 per surviving pair; peak = 256 CUs x one DS op of 2 dwords "
+                                              f"per {CYC_DS_2DWORD} cycles (MI355X_MICROARCH.md LDS table; profiles/r02_lds_rate.txt measures 4.4-5.1); "
+                                              "row_bytes_per_s = the 2 x 16 KiB of HLL registers per pair, served mostly by L2/MALL"}
+        if n_degenerate:
+            out["config"]["degenerate_genomes"] = n_degenerate
 
+    extras = rank == 0 and world == 1 and not args.no_extras
     # ---- the literal north_star kernel (ALGO_STREAM: query tile staged in LDS, candidates streamed row-major, lane-mask
     # reduction) measured beside the default algorithm, outside the timed region (rank 0, N=1, same inputs)
-    if rank == 0 and world == 1 and args.algo == "auto" and not two_stage:
+    if extras and args.algo == "auto" and not two_stage:
         for _ in range(2):
             sel.run(cfg.tau, mode, n_rows, n_bands, algo=pkg.ALGO_STREAM, fetch=False)
         sel.timing(True)
@@ -343,10 +399,38 @@ def main():
         except Exception:
             pass
         out["stream_kernel"] = {"algo": "stream", "pairs_per_s": s_st["evaluated"] / dts, "ms_per_step": dts * 1e3, "selected_pairs": s_st["selected"],
-                                "roofline": {"bound": "hbm", "kernel": "smh_stream_kernel", "achieved": s_bytes / (s_ms * 1e-3) / 1e9,
-                                             "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": s_bytes / (s_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                                             "traffic": s_traffic, "avg_launch_ms": s_ms, "algorithmic_bytes_per_launch": s_bytes}}
+                                "bucket_pair_comparisons_per_s_executed": s_st["evaluated"] * cfg.m / (s_ms * 1e-3),
+                                "avg_launch_ms": s_ms, "traffic": s_traffic,
+                                "hbm_algorithmic": {"achieved_GBs": s_bytes / (s_ms * 1e-3) / 1e9, "ratio": s_bytes / (s_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
+                                "roofline": stream_issue_roofline(cfg.m, n_rows, s_st["evaluated"], s_ms)}
         sel.timing(False)
+
+    # ---- the harder variant of the same configuration, measured beside the main line (never instead of it)
+    if extras and not args.hard and not two_stage and args.algo == "auto":
+        aux_h = aux_t.clone()
+        n_deg = pkg.harden(aux_h)
+        with pkg.Selector(local_rank) as s3:
+            s3.attach(hll_t, aux_h, cards_t)
+            for _ in range(2):
+                s3.run(cfg.tau, mode, n_rows, n_bands, fetch=False)
+            torch.cuda.synchronize(dev)
+            th = time.perf_counter()
+            kh = 10
+            for _ in range(kh):
+                s3.run(cfg.tau, mode, n_rows, n_bands, fetch=False)
+            torch.cuda.synchronize(dev)
+            dth = (time.perf_counter() - th) / kh
+            hs = s3.stats()
+            s3.timing(1)
+            for _ in range(3):
+                s3.run(cfg.tau, mode, n_rows, n_bands, fetch=False)
+            hk = {k: s3.kernel_ms(k) for k in ("sigbuild", "join", "verify", "group", "hist", "select")}
+            s3.timing(0)
+        out["harder_workload"] = {"workload": f"{cfg.name} with {n_deg} of {n_genomes} genomes degenerate (buckets mod 2): pairs among them pass a band by chance",
+                                  "value": hs["evaluated"] / dth, "unit": "pairs/s", "ms_per_step": dth * 1e3,
+                                  "stage1_survivors": hs["survivors"], "survivor_fraction": hs["survivors"] / max(1, hs["evaluated"]),
+                                  "selected_pairs": hs["selected"], "kernel_ms": {k: v for k, v in hk.items() if v > 0}}
+        del aux_h
 
     # ---- CPU baseline: the oracle (OpenMP port of selection.cpp:270-291 / time_smh.cpp:229-257) on a bounded sample
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -356,33 +440,36 @@ def main():
         cores = os.cpu_count() or 1
         use_cb = mode == pkg.MODE_CB_SMH
 
-        def cpu_run(ns, reps=1):
+        def cpu_run(ns, threads, reps=1):
             h = hll_t[:ns].cpu().numpy()
             a = aux_t[:ns].cpu().numpy().view(np.uint64)
             ah = aux_hll_t[:ns].cpu().numpy() if two_stage else None
             c = cards[:ns]
             t = time.perf_counter()
             for _ in range(reps):
-                pairs, s = orc.select(h, a, c, cfg.tau, n_rows, n_bands, use_cb=use_cb, threads=cores,
+                pairs, s = orc.select(h, a, c, cfg.tau, n_rows, n_bands, use_cb=use_cb, threads=threads,
                                       criterion=3 if two_stage else 0, aux_hll=ah, p_aux=cfg.p_aux or 8)
             return time.perf_counter() - t, s["evaluated"] * reps, len(pairs)
 
-        ns = min(n_genomes, 2000)
-        t_probe, ev, _ = cpu_run(ns)
-        rate = ev / max(t_probe, 1e-9)
-        ns = int(min(n_genomes, max(ns, math.sqrt(2 * rate * args.cpu_seconds))))
-        t1, ev1, _ = cpu_run(ns)                                 # one pass at the chosen size, then repeat to fill the budget
-        reps = int(max(1, min(200, args.cpu_seconds / max(t1, 1e-3))))
-        t_probe, ev, nsel = cpu_run(ns, reps)
-        out["cpu_baseline"] = {"value": ev / t_probe, "unit": "pairs/s", "cores": cores, "kind": "port",
-                               "sample": f"first {ns} genomes (rank order) of the same set, {reps} pass(es): {ev} pairs in {t_probe:.2f} s; "
-                                         f"oracle/liboracle.so orc_select = OpenMP port of src/selection.cpp:270-291, schedule(dynamic) over rows"}
+        def cpu_row(threads):
+            ns = min(n_genomes, 2000)
+            t_probe, ev, _ = cpu_run(ns, threads)
+            rate = ev / max(t_probe, 1e-9)
+            ns = int(min(n_genomes, max(ns, math.sqrt(2 * rate * args.cpu_seconds))))
+            t1, ev1, _ = cpu_run(ns, threads)                    # one pass at the chosen size, then repeat to fill the budget
+            reps = int(max(1, min(200, args.cpu_seconds / max(t1, 1e-3))))
+            t_probe, ev, nsel = cpu_run(ns, threads, reps)
+            return {"value": ev / t_probe, "unit": "pairs/s", "cores": threads, "kind": "port",
+                    "sample": f"first {ns} genomes (rank order) of the same set, {reps} pass(es): {ev} pairs in {t_probe:.2f} s; "
+                              f"oracle/liboracle.so orc_select = OpenMP port of src/selection.cpp:270-291, schedule(dynamic) over rows"}
+
+        out["cpu_baseline"] = cpu_row(cores)
+        out["cpu_baseline_8t"] = cpu_row(min(8, cores))          # the reference's default thread count (selection.cpp:79)
         # ---- the REFERENCE's own CPU program (oracle/_ref/selection, built from the unmodified sources in the
         # authoring container and shipped prebuilt) on sketch FILES written from the same set: two sizes, so that
         # file loading cancels in the difference (the program does not time its loop separately).
         ref_bin = ROOT / "oracle" / "_ref" / "selection"
-        if ref_bin.exists() and not use_cb is None and not two_stage:
-            import subprocess
+        if ref_bin.exists() and not two_stage:
             import tempfile
             try:
                 host = pkg.host_lib()
@@ -429,6 +516,24 @@ def main():
     sel.close()
     if dist_on:
         dist.destroy_process_group()
+
+
+def stream_issue_roofline(m, n_rows, pairs, launch_ms):
+    """the stream kernel's binding resource: instruction issue.  Model counts per (query, candidate) pair from the ISA
+    (csrc/kernel_stream.cuh); filled in with the kernel's current shape."""
+    from cuda_selection_criteria_amd import stream_model
+    mdl = stream_model(m, n_rows)
+    if launch_ms <= 0:
+        return None
+    salu = pairs * mdl["salu_per_pair"] / (launch_ms * 1e-3)
+    valu = pairs * mdl["valu_wave_instr_per_pair"] / (launch_ms * 1e-3)
+    salu_peak = 256 * SHADER_HZ                               # one scalar instruction per cycle per CU
+    valu_peak = N_SIMD * SHADER_HZ / CYC_VALU_FULL            # v_cmp / DPP / ballot forms: full-cost instructions
+    bound = "salu_issue" if salu / salu_peak >= valu / valu_peak else "valu_issue"
+    return {"bound": bound, "kernel": "smh_stream_kernel", "unit": "G instr/s",
+            "achieved": (salu if bound == "salu_issue" else valu) / 1e9, "peak": (salu_peak if bound == "salu_issue" else valu_peak) / 1e9,
+            "frac": max(salu / salu_peak, valu / valu_peak), "salu_issue_frac": salu / salu_peak, "valu_issue_frac": valu / valu_peak,
+            "model": mdl}
 
 
 if __name__ == "__main__":

@@ -11,7 +11,7 @@ constexpr int kWave = 64;
 constexpr int kBlock = 256;            // 4 waves
 constexpr int kWavesPerBlock = kBlock / kWave;
 constexpr int kChunk = 256;            // candidates per stage-1 block
-constexpr int kQueryVgprBudget = 32;   // u64x2 query registers per lane  (Q * NCH)
+constexpr int kQueryVgprBudget = 28;   // u64x2 query registers per lane  (Q * NCH): 112 VGPRs + the candidate double buffer fit 168 without scratch
 
 // ---------------------------------------------------------------------------------------------
 // device-side counters of one pass

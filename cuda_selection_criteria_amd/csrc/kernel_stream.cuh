@@ -5,44 +5,87 @@
 namespace {
 
 // ---------------------------------------------------------------------------------------------
-// Band predicate on lane masks.  A candidate chunk of 128 buckets is held as one u64x2 per lane:
-// lane l owns buckets (2l, 2l+1).  m0/m1 are the v_cmp_eq_u64 lane masks of the even/odd bucket.
-// A band of r = 2^LOG2R consecutive buckets is, for r >= 2, r/2 consecutive lanes of (m0 & m1).
-// Returns a mask with a bit set for every fully equal band (r <= 128).
+// ALGO_STREAM -- the literal design of BASELINE.json's north_star: the m-bucket sketches are read coalesced from HBM, one
+// tile of query sketches is staged in LDS per workgroup, and the per-pair bucket compares are reduced with wavefront
+// primitives (v_cmp_eq_u64 lane masks, scalar AND/shift folds).
+//
+// Lane <-> bucket mapping.  A sketch is m = 64 * B buckets; lane l owns the B CONTIGUOUS buckets [l*B, (l+1)*B), i.e.
+// NCH = B/2 registers of type u64x2.  To keep the loads coalesced (lane l reading 16 bytes next to lane l+1's) the pass
+// first writes a bucket-interleaved copy of the sketch array (stream_interleave_kernel):
+//     P[row][c*64 + l] = R[row][l*NCH + c]        (u64x2 units, c < NCH, l < 64)
+// so that `global_load_dwordx4` number c of a wave fetches 1 KiB contiguous and hands lane l its buckets l*B + 2c, 2c+1.
+// With the band of r consecutive buckets inside ONE lane (r <= B) or spanning r/B whole lanes (r >= B), the band predicate is
+//     r >= B:  M = AND of the 2*NCH v_cmp_eq_u64 lane masks (bit l = "all of lane l's buckets equal"), then a band is r/B
+//              consecutive set bits at an aligned position: log2(r/B) shift-AND steps + one alignment mask, on the scalar unit;
+//     r <  B:  per group of r buckets inside the lane the AND of its masks, OR over the groups.
+// Per (query, candidate): 2*NCH vector compares and ~2*NCH scalar ANDs -- at m = 512, r = 8 (BASELINE configs[2]): 8 + ~10.
+// (Round 1 mapped lane l to buckets (2l, 2l+1) of each 128-bucket chunk: a band then always straddled lanes and every
+//  CHUNK needed its own shift-AND fold -- 33 scalar instructions per pair, 81 % of the scalar issue rate, 3.35 ms at cfg3.)
 // ---------------------------------------------------------------------------------------------
-template <int HALF>
+template <int L>
 __host__ __device__ constexpr u64 align_mask() {
-    // one bit at every multiple of HALF
+    // one bit at every multiple of L
     u64 v = 0;
-    for (int b = 0; b < 64; b += HALF) v |= 1ull << b;
+    for (int b = 0; b < 64; b += L) v |= 1ull << b;
     return v;
 }
 
-template <int LOG2R>
-__device__ __forceinline__ u64 band_fold(u64 m0, u64 m1) {
-    if constexpr (LOG2R == 0) {
-        return m0 | m1;
-    } else {
-        constexpr int HALF = 1 << (LOG2R - 1);
-        u64 t = m0 & m1;
+__global__ __launch_bounds__(kBlock)
+void stream_interleave_kernel(const u64x2* __restrict__ in, u64x2* __restrict__ out, long long total, int nch) {
+    const long long o = (long long)blockIdx.x * kBlock + threadIdx.x;
+    if (o >= total) return;
+    const int per_row = nch * kWave;
+    const long long row = o / per_row;
+    const int rem = (int)(o - row * per_row);
+    const int c = rem / kWave, l = rem % kWave;
+    out[o] = in[row * per_row + l * nch + c];
+}
+
+template <int NCH, int LOG2R>
+__device__ __forceinline__ bool stream_band_pass(const u64x2 (&cand)[NCH], const u64x2 (&q)[NCH]) {
+    constexpr int B = 2 * NCH, R = 1 << LOG2R;
+    if constexpr (R >= B) {
+        u64 M = ~0ull;
 #pragma unroll
-        for (int s = 1; s < HALF; s <<= 1) t &= t >> s;
-        return t & align_mask<HALF>();
+        for (int c = 0; c < NCH; ++c) {
+            M &= __ballot(cand[c].x == q[c].x);
+            M &= __ballot(cand[c].y == q[c].y);
+        }
+        constexpr int L = R / B;                      // lanes per band
+        if constexpr (L >= 64) {
+            return M == ~0ull;
+        } else {
+#pragma unroll
+            for (int s = 1; s < L; s <<= 1) M &= M >> s;
+            return (M & align_mask<L>()) != 0;
+        }
+    } else {
+        u64 any = 0;
+#pragma unroll
+        for (int g = 0; g < B / R; ++g) {
+            u64 Mg = ~0ull;
+#pragma unroll
+            for (int j = g * R; j < (g + 1) * R; ++j)
+                Mg &= (j & 1) ? __ballot(cand[j >> 1].y == q[j >> 1].y) : __ballot(cand[j >> 1].x == q[j >> 1].x);
+            any |= Mg;
+        }
+        return any != 0;
     }
 }
 
 // ---------------------------------------------------------------------------------------------
-// smh_stream_kernel<NCH, LOG2R>: m = 128*NCH buckets, bands of 2^LOG2R rows (LOG2R == 7: r >= 128,
-// runtime r_rt, a band covers r_rt/128 whole chunks).
-//   block  = 4 waves; one block = (query tile of Q = 32/NCH rows) x (chunk of kChunk candidates)
-//   LDS    = the Q query sketches (32 KiB), staged once per block, then copied to VGPRs by each wave
-//   stream = each wave walks its candidates (stride 4), NCH x global_load_dwordx4 per candidate
+// smh_stream_kernel<NCH, LOG2R>: m = 128*NCH buckets, bands of 2^LOG2R rows.
+//   block  = 4 waves; one block = (query tile of Q = 28/NCH rows) x (chunk of kChunk candidates)
+//   LDS    = the Q query sketches (28 KiB), staged once per block with coalesced 16-B loads, then copied to VGPRs by each wave
+//   stream = each wave walks its candidates (stride 4), NCH x global_load_dwordx4 (1 KiB each) per candidate, one candidate ahead
 // blockIdx.x -> (tile = b % n_tiles, chunk = b / n_tiles): blocks b and b+8 (same XCD under round-robin
 // dispatch) work on the same candidate chunk, so the chunk is served by that XCD's L2.
+// Registers: Q*NCH = 28 query + 2*NCH candidate u64x2 (112 + 32 VGPRs at NCH = 4): no scratch under the 168-VGPR cap of
+// 3 waves per SIMD (round 1 held 32 query registers and spilled 10 VGPRs: 222 MB of scratch writes per launch).
 // ---------------------------------------------------------------------------------------------
 template <int NCH, int LOG2R>
-__global__ __launch_bounds__(kBlock, (NCH <= 4 ? 3 : 2))      // 3 waves/SIMD = at most 168 VGPRs (measured: 2 waves cost 17 %)
-void smh_stream_kernel(const u64x2* __restrict__ aux, int n, int r_rt,
+__global__ __launch_bounds__(kBlock, (NCH <= 4 ? 3 : 2))
+void smh_stream_kernel(const u64x2* __restrict__ aux, int n,
                        const int* __restrict__ hi, const PassCounters* __restrict__ pc_in,
                        RowMap rm, int n_tiles, int chunk_base,
                        selhip_int2_t* __restrict__ surv, u64 surv_cap, PassCounters* __restrict__ pc) {
@@ -104,35 +147,9 @@ void smh_stream_kernel(const u64x2* __restrict__ aux, int n, int r_rt,
 #pragma unroll
             for (int c = 0; c < NCH; ++c) nxt[c] = row[c * kWave];
         }
-
 #pragma unroll
         for (int a = 0; a < Q; ++a) {
-            bool pass;
-            if constexpr (LOG2R < 7) {
-                u64 acc = 0;
-#pragma unroll
-                for (int c = 0; c < NCH; ++c) {
-                    u64 m0 = __ballot(cand[c].x == q[a][c].x);
-                    u64 m1 = __ballot(cand[c].y == q[a][c].y);
-                    acc |= band_fold<LOG2R>(m0, m1);
-                }
-                pass = acc != 0;
-            } else {
-                // r_rt >= 128: a band is r_rt/128 consecutive chunks, all 128 buckets of each equal
-                const int G = r_rt >> 7;
-                pass = false;
-                bool run = true;
-#pragma unroll
-                for (int c = 0; c < NCH; ++c) {
-                    u64 m0 = __ballot(cand[c].x == q[a][c].x);
-                    u64 m1 = __ballot(cand[c].y == q[a][c].y);
-                    bool full = (m0 & m1) == ~0ull;
-                    if ((c % G) == 0) run = true;
-                    run = run && full;
-                    if ((c % G) == G - 1 && run) pass = true;
-                }
-            }
-            if (pass) {
+            if (stream_band_pass<NCH, LOG2R>(cand, q[a])) {
                 const int i = i0 + a;
                 if (i < i_end && k > i && k >= z0 && k <= hi[i]) app.push_uniform(i, k, lane);
             }

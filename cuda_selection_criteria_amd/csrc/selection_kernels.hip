@@ -130,6 +130,7 @@ struct selhip_ctx {
     DevBuf<uint8_t> own_aux_hll;
     int p_aux = 0;
     int criterion = 0;
+    DevBuf<u64> aux_il;                 // ALGO_STREAM: bucket-interleaved copy of the sketches (kernel_stream.cuh)
     DevBuf<uint32_t> sigQ, sigT, sigP, sigG;  // ALGO_SIG: band signatures, genome-major / band-major / band-major 16-bit pairs / genome-major 16-bit pairs
     DevBuf<u64> hj_keys_in, hj_keys_out;   // ALGO_HASHJOIN: (band << 32 | signature) keys, before / after the sort
     DevBuf<int> hj_vals_in, hj_vals_out;   //                genome ranks carried by the keys
@@ -248,7 +249,7 @@ RowMap row_map(const selhip_ctx* c, int rb, int re) {
 
 // ---- stage-1 dispatch ------------------------------------------------------------------------
 template <int NCH, int LOG2R>
-hipError_t launch_stream(selhip_ctx* c, const StageIO& io, int r_rt, int row_begin, int row_end) {
+hipError_t launch_stream(selhip_ctx* c, const StageIO& io, int row_begin, int row_end) {
     constexpr int Q = kQueryVgprBudget / NCH;
     const int n = (int)c->n;
     const RowMap rm = row_map(c, row_begin, row_end);
@@ -262,24 +263,17 @@ hipError_t launch_stream(selhip_ctx* c, const StageIO& io, int r_rt, int row_beg
     const long long blocks = (long long)n_tiles * n_chunks;
     if (blocks > 0x7FFFFFFFll) return hipErrorInvalidValue;
     hipLaunchKernelGGL((smh_stream_kernel<NCH, LOG2R>), dim3((unsigned)blocks), dim3(kBlock), 0, io.st,
-                       reinterpret_cast<const u64x2*>(c->d_aux), n, r_rt, c->hi.p, c->pc.p,
+                       reinterpret_cast<const u64x2*>(c->aux_il.p), n, c->hi.p, c->pc.p,
                        rm, n_tiles, chunk_base, io.surv, io.cap, io.pc);
     return hipGetLastError();
 }
 
-template <int NCH>
-hipError_t launch_stream_r(selhip_ctx* c, const StageIO& io, int n_rows, int rb, int re) {
-    const int l = n_rows >= 128 ? 7 : ilog2(n_rows);
-    switch (l) {
-        case 0: return launch_stream<NCH, 0>(c, io, n_rows, rb, re);
-        case 1: return launch_stream<NCH, 1>(c, io, n_rows, rb, re);
-        case 2: return launch_stream<NCH, 2>(c, io, n_rows, rb, re);
-        case 3: return launch_stream<NCH, 3>(c, io, n_rows, rb, re);
-        case 4: return launch_stream<NCH, 4>(c, io, n_rows, rb, re);
-        case 5: return launch_stream<NCH, 5>(c, io, n_rows, rb, re);
-        case 6: return launch_stream<NCH, 6>(c, io, n_rows, rb, re);
-        default: return launch_stream<NCH, 7>(c, io, n_rows, rb, re);
-    }
+// LOG2R runs over 0 .. log2(m) = log2(128 * NCH)
+template <int NCH, int LOG2R>
+hipError_t launch_stream_r(selhip_ctx* c, const StageIO& io, int l, int rb, int re) {
+    if (l == LOG2R) return launch_stream<NCH, LOG2R>(c, io, rb, re);
+    if constexpr ((1 << LOG2R) < 128 * NCH) return launch_stream_r<NCH, LOG2R + 1>(c, io, l, rb, re);
+    return hipErrorInvalidValue;
 }
 
 bool stream_supported(int m, int n_rows) {
@@ -288,12 +282,14 @@ bool stream_supported(int m, int n_rows) {
 
 hipError_t launch_stage1(selhip_ctx* c, const StageIO& io, int n_rows, int n_bands, int rb, int re) {
     if (stream_supported(c->m, n_rows)) {
-        switch (c->m / 128) {
-            case 1: return launch_stream_r<1>(c, io, n_rows, rb, re);
-            case 2: return launch_stream_r<2>(c, io, n_rows, rb, re);
-            case 4: return launch_stream_r<4>(c, io, n_rows, rb, re);
-            case 8: return launch_stream_r<8>(c, io, n_rows, rb, re);
-            case 16: return launch_stream_r<16>(c, io, n_rows, rb, re);
+        const int nch = c->m / 128;
+        const int l = ilog2(n_rows);
+        switch (nch) {
+            case 1: return launch_stream_r<1, 0>(c, io, l, rb, re);
+            case 2: return launch_stream_r<2, 0>(c, io, l, rb, re);
+            case 4: return launch_stream_r<4, 0>(c, io, l, rb, re);
+            case 8: return launch_stream_r<8, 0>(c, io, l, rb, re);
+            case 16: return launch_stream_r<16, 0>(c, io, l, rb, re);
         }
     }
     const RowMap rm = row_map(c, rb, re);
@@ -622,6 +618,14 @@ int enqueue_pass(selhip_ctx* c) {
                            c->d_cards, n, tau, c->mode == SELHIP_MODE_CB_SMH ? 1 : 0, row_map(c, rb, re), c->ecard.p, c->hi.p, pc0,
                            (c->p == 14 && c->group_stage2) ? c->csr_cnt.p : nullptr, (int)c->cand_begin);
         HIPCHK(&c->err, hipGetLastError());
+        if (smh_crit && stream_supported(c->m, c->n_rows)) {
+            // ALGO_STREAM: the bucket-interleaved copy of the sketches (lane l = buckets [l*B, (l+1)*B)), rebuilt every pass
+            const int nch = c->m / 128;
+            const long long total = (long long)c->n * nch * kWave;
+            hipLaunchKernelGGL(stream_interleave_kernel, dim3((unsigned)((total + kBlock - 1) / kBlock)), dim3(kBlock), 0, c->stream,
+                               reinterpret_cast<const u64x2*>(c->d_aux), reinterpret_cast<u64x2*>(c->aux_il.p), total, nch);
+            HIPCHK(&c->err, hipGetLastError());
+        }
     }
 
     const int chunks = pipeline_chunks(c);
@@ -779,6 +783,9 @@ int ensure_scratch(selhip_ctx* c, size_t surv_cap, size_t res_cap) {
         const size_t n_pad = (((size_t)c->n + kWave - 1) / kWave) * kWave;
         const size_t nb = (size_t)std::max(c->n_bands, 1);
         const bool hash = c->algo == SELHIP_ALGO_HASHJOIN;
+        const bool smh = c->criterion == SELHIP_CRIT_SMH_A || c->criterion == SELHIP_CRIT_HLL_A_SMH_A;
+        const bool sig_path = hash || ((c->algo == SELHIP_ALGO_SIG || c->algo == SELHIP_ALGO_AUTO) && sig_supported(c->m, c->n_rows, c->n_bands));
+        if (smh && !sig_path && stream_supported(c->m, c->n_rows)) HIPCHK(&c->err, c->aux_il.ensure((size_t)c->n * c->m));
         if (nb <= 128 || hash) {
             HIPCHK(&c->err, c->sigQ.ensure((size_t)c->n * nb));
             HIPCHK(&c->err, c->sigT.ensure(n_pad * nb));
@@ -859,7 +866,7 @@ void selhip_ctx_destroy(selhip_ctx* c) {
     c->own_hll.release(); c->own_aux.release(); c->own_cards.release();
     c->ecard.release(); c->hi.release(); c->pc.release(); c->seg_cnt.release(); c->surv.release();
     c->counts.release(); c->results.release(); c->self_pairs.release();
-    c->cand.release(); c->sigQ.release(); c->sigT.release(); c->sigP.release(); c->sigG.release(); c->fin.release(); c->own_aux_hll.release();
+    c->aux_il.release(); c->cand.release(); c->sigQ.release(); c->sigT.release(); c->sigP.release(); c->sigG.release(); c->fin.release(); c->own_aux_hll.release();
     c->hj_keys_in.release(); c->hj_keys_out.release(); c->hj_vals_in.release(); c->hj_vals_out.release(); c->hj_tmp.release();
     c->csr_cnt.release(); c->csr_start.release(); c->grouped.release(); c->scan_tmp.release();
     if (c->h_pc) (void)hipHostFree(c->h_pc);

@@ -1,9 +1,11 @@
 """Multi-GPU layer: one process per GPU (torch.distributed; backend "nccl" = RCCL over xGMI on the
 GPU box, "gloo" in CPU tests).  The pair space shards naturally -- every pair is independent given
-read-only sketches -- so each rank holds a full replica of the sketches, runs the
-hot path on its contiguous range of query rows (equal PAIR counts, not equal row counts), and the only
-exchange step is the gather of the selected-pair lists: all_gather of the counts, then all_gather of
-the fixed-capacity record buffers.  No collective touches the sketch data path."""
+read-only sketches -- so each rank holds a full replica of the sketches and evaluates
+the query rows it owns.  Ownership is an INTERLEAVE: rows are cut into blocks of `block` rows (128) and block b
+belongs to rank b mod world (selhip_ctx_set_row_interleave; `interleave_owner` below) -- every rank then gets the
+same share of pairs AND of survivors whatever the shape of the (triangular or CB-banded) pair space; the
+contiguous equal-pair cut (`shard_rows`, libselhost selhost_shard_rows) stays for callers that want row ranges.
+The only exchange step is the gather of the selected-pair lists.  No collective touches the sketch data path."""
 from __future__ import annotations
 
 import ctypes as C
@@ -17,22 +19,39 @@ from .selection import PAIR_DTYPE
 
 def cb_bounds(cards: np.ndarray, tau: float) -> np.ndarray:
     """hi[i] = last rank k that still passes CB against row i (criteria_sketch.hpp:45-49 on the
-    size_t-truncated cardinalities of selection.cpp:275,280; monotone because cards are ascending)."""
+    size_t-truncated cardinalities of selection.cpp:275,280; monotone because cards are ascending).
+    One binary search per row, all rows at once (log2 N vectorised steps, the same IEEE double divide as the predicate)."""
     e = np.asarray(cards, dtype=np.float64).astype(np.uint64).astype(np.float64)   # (double)(size_t)card
     n = e.shape[0]
     tau64 = float(np.float32(tau))
-    hi = np.empty(n, dtype=np.int32)
-    for i in range(n):
-        lo_, hi_ = i, n - 1
-        while lo_ < hi_:
-            mid = (lo_ + hi_ + 1) // 2
-            ok = e[mid] == 0 or (e[i] / e[mid] >= tau64)
-            if ok:
-                lo_ = mid
-            else:
-                hi_ = mid - 1
-        hi[i] = lo_
-    return hi
+    lo = np.arange(n, dtype=np.int64)                     # invariant: the predicate holds at lo (k = i counts as true)
+    hi = np.full(n, n - 1, dtype=np.int64)
+    ei = e.copy()
+    with np.errstate(divide="ignore", invalid="ignore"):
+        while True:
+            act = lo < hi
+            if not act.any():
+                break
+            mid = (lo + hi + 1) // 2
+            em = e[mid]
+            ok = (em == 0) | (ei / em >= tau64)
+            lo = np.where(act & ok, mid, lo)
+            hi = np.where(act & ~ok, mid - 1, hi)
+    return lo.astype(np.int32)
+
+
+def interleave_owner(rows, block: int, world: int):
+    """rank that owns query row(s) `rows` under the row interleave (block b -> rank b mod world)"""
+    return (np.asarray(rows, dtype=np.int64) // block) % world
+
+
+def interleave_pair_counts(n: int, block: int, world: int, hi: Optional[np.ndarray] = None, z0: int = 0) -> np.ndarray:
+    """pairs each rank evaluates under the row interleave (the product's own counter is stats()['evaluated'])"""
+    i = np.arange(n, dtype=np.int64)
+    h = np.full(n, n - 1, dtype=np.int64) if hi is None else np.asarray(hi, dtype=np.int64)
+    cnt = np.maximum(h - np.maximum(i + 1, z0) + 1, 0)
+    own = interleave_owner(i, block, world)
+    return np.array([cnt[own == r].sum() for r in range(world)], dtype=np.int64)
 
 
 def first_nonzero(cards: np.ndarray) -> int:

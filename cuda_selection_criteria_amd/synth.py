@@ -106,3 +106,32 @@ def synth_device(cfg: SynthConfig, device: int = 0, sort: bool = True):
         check(lib.selhip_device_synchronize())
         cards_s = cards[perm_t.long()].contiguous()
         return hll_s, aux_s, cards_s, perm, aux_hll_s
+
+
+def harden(aux, frac: float = 0.25, alphabet: int = 2, seed: int = 0xD15EA5E) -> int:
+    """The "harder" workload: a seeded `frac` of the genomes (by position in `aux`) gets degenerate SuperMinHash buckets
+    (values mod `alphabet`), so that pairs among them pass a band by chance -- alphabet 2 and bands of 8 rows: 22 % of those
+    pairs -- i.e. ~frac^2 * 0.22 of ALL pairs reach stage 2 instead of the 0.09 % of the plain recipe.  Works in place on a
+    numpy uint64 array or on a torch int64 tensor (device or host); returns the number of degenerate genomes."""
+    n = aux.shape[0]
+    mask = np.random.default_rng(seed).random(n) < frac
+    if isinstance(aux, np.ndarray):
+        aux[mask] = aux[mask] % np.uint64(alphabet)
+    else:
+        import torch
+        idx = torch.from_numpy(np.nonzero(mask)[0]).to(aux.device)
+        aux[idx] = aux[idx] % alphabet              # int64 view of u64 bucket values < 2^32
+    return int(mask.sum())
+
+
+def stream_model(m: int, n_rows: int) -> dict:
+    """instruction counts of smh_stream_kernel per (query, candidate) pair, from its ISA (csrc/kernel_stream.cuh): lane l owns
+    B = m/64 contiguous buckets; B v_cmp_eq_u64; B-1 s_and_b64 (r >= B: + 2 per shift-AND step over r/B lanes); 8 scalar
+    instructions for the test and the branch"""
+    B = max(2, m // 64)
+    steps = 0
+    L = n_rows // B
+    while L > 1:
+        steps += 1
+        L //= 2
+    return {"valu_wave_instr_per_pair": B, "salu_per_pair": (B - 1) + 2 * steps + 8, "buckets_per_lane": B}

@@ -23,7 +23,7 @@
 enum Kind { K_FMA_F32, K_ADD_U32, K_XOR_B32, K_PK_MIN_U16, K_XOR_DPP, K_MIN3_U32, K_PK_FMA_F32, K_OR3_B32, K_JOINMIX, K_JOINMIX_DEP,
             K_SAD_U16, K_PERM_B32, K_CMP_EQ_U32, K_FMA_F64, K_MQSAD_U32_U8, K_MUL_LO_U32, K_PK_ADD_U16,
             K_MIN_U32, K_AND_B32, K_XOR_SGPR, K_LSHRREV_B32, K_MOV_DPP, K_AND_OR_B32, K_BFI_B32, K_JOINMIX_SGPR, K_MIN_U16, K_XOR_SDWA, K_ADD_F32, K_MAX_U32,
-            K_MIX_ALT, K_MIX_G4, K_MIX_G8, K_MIX_XOR_AND, K_MIX_XOR_MIN16, K_OR_B32, K_SUB_U32, K_MIN_I32, K_MIN_F32, K_MUL_F32, K_MOV_B32, K_NKINDS };
+            K_MIX_ALT, K_MIX_G4, K_MIX_G8, K_MIX_XOR_AND, K_MIX_XOR_MIN16, K_OR_B32, K_SUB_U32, K_MIN_I32, K_MIN_F32, K_MUL_F32, K_MOV_B32, K_CMP_EQ_U64, K_CMP_EQ_U32_SGPR, K_NKINDS };
 
 const char* kNames[K_NKINDS] = {
     "v_fma_f32", "v_add_u32", "v_xor_b32", "v_pk_min_u16", "v_xor_b32_dpp row_newbcast", "v_min3_u32", "v_pk_fma_f32",
@@ -32,7 +32,7 @@ const char* kNames[K_NKINDS] = {
     "v_min_u32", "v_and_b32", "v_xor_b32 v, s, v (SGPR operand)", "v_lshrrev_b32", "v_mov_b32_dpp row_newbcast", "v_and_or_b32", "v_bfi_b32",
     "join mix 2: v_xor_b32 (SGPR query) + v_pk_min_u16", "v_min_u16", "v_xor_b32_sdwa", "v_add_f32", "v_max_u32",
     "mix: v_xor_b32 (VGPR) / v_pk_min_u16 alternating", "mix: 4 x v_xor_b32 then 4 x v_pk_min_u16", "mix: 8 x v_xor_b32 then 8 x v_pk_min_u16",
-    "mix: v_xor_b32 / v_and_b32 alternating (both 2-cycle)", "mix: v_xor_b32 / v_min_u16 alternating (both 2-cycle)", "v_or_b32", "v_sub_u32", "v_min_i32", "v_min_f32", "v_mul_f32", "v_mov_b32"};
+    "mix: v_xor_b32 / v_and_b32 alternating (both 2-cycle)", "mix: v_xor_b32 / v_min_u16 alternating (both 2-cycle)", "v_or_b32", "v_sub_u32", "v_min_i32", "v_min_f32", "v_mul_f32", "v_mov_b32", "v_cmp_eq_u64 -> SGPR pair", "v_cmp_eq_u32 -> SGPR pair"};
 
 template <int KIND>
 __global__ __launch_bounds__(256) void rate_kernel(uint32_t* __restrict__ out, unsigned long long* __restrict__ cyc, int iters) {
@@ -41,6 +41,9 @@ __global__ __launch_bounds__(256) void rate_kernel(uint32_t* __restrict__ out, u
 #pragma unroll
     for (int i = 0; i < 8; ++i) { a[i] = threadIdx.x * 2654435761u + i * 97u + 1u; q[i] = blockIdx.x * 40503u + i * 77u + threadIdx.x + 3u; t[i] = 0; }
     uint32_t sq[8];
+    unsigned long long sm[4] = {0, 0, 0, 0}, dq[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) dq[i] = ((unsigned long long)threadIdx.x << 32) | (unsigned)(i * 2654435761u);
 #pragma unroll
     for (int i = 0; i < 8; ++i) sq[i] = (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * 7919u + i * 104729u + (uint32_t)iters));
     double dd[8], d1 = 1.0000001;
@@ -236,6 +239,14 @@ __global__ __launch_bounds__(256) void rate_kernel(uint32_t* __restrict__ out, u
 #define X(i) asm volatile("v_mov_b32 %0, %1" : "=v"(a[i]) : "v"(q[i]));
                 REP8(X)
 #undef X
+            } else if constexpr (KIND == K_CMP_EQ_U64) {
+#define X(i) asm volatile("v_cmp_eq_u64 %0, %1, %2" : "=s"(sm[i & 3]) : "v"(dq[i]), "v"(dq[(i + 3) & 7]));
+                REP8(X)
+#undef X
+            } else if constexpr (KIND == K_CMP_EQ_U32_SGPR) {
+#define X(i) asm volatile("v_cmp_eq_u32 %0, %1, %2" : "=s"(sm[i & 3]) : "v"(a[i]), "v"(q[i]));
+                REP8(X)
+#undef X
             } else if constexpr (KIND == K_PK_ADD_U16) {
 #define X(i) asm volatile("v_pk_add_u16 %0, %0, %1" : "+v"(a[i]) : "v"(q[i]));
                 REP8(X)
@@ -244,7 +255,7 @@ __global__ __launch_bounds__(256) void rate_kernel(uint32_t* __restrict__ out, u
         }
     }
     const unsigned long long c1 = __builtin_readcyclecounter();
-    uint32_t s = 0;
+    uint32_t s = (uint32_t)(sm[0] + sm[1] + sm[2] + sm[3]);
 #pragma unroll
     for (int i = 0; i < 8; ++i) s += (uint32_t)dd[i];
 #pragma unroll
@@ -365,6 +376,8 @@ int main() {
         run_kind<K_MIN_F32>(d_out, d_cyc, W, iters, ticks_per_s, shader_hz);
         run_kind<K_MUL_F32>(d_out, d_cyc, W, iters, ticks_per_s, shader_hz);
         run_kind<K_MOV_B32>(d_out, d_cyc, W, iters, ticks_per_s, shader_hz);
+        run_kind<K_CMP_EQ_U64>(d_out, d_cyc, W, iters, ticks_per_s, shader_hz);
+        run_kind<K_CMP_EQ_U32_SGPR>(d_out, d_cyc, W, iters, ticks_per_s, shader_hz);
     }
     return 0;
 }

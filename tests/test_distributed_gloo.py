@@ -1,6 +1,9 @@
-"""N>1 path on CPU: world_size-2 gloo.  The GPU compute is replaced by the CPU oracle as a stand-in
-producer (this is a test of the sharding + gather logic in cuda_selection_criteria_amd/distributed.py,
-which is backend-agnostic); the union of the shards must equal the single-rank answer."""
+"""N>1 path on CPU: world_size-2 gloo.  The GPU compute is replaced by the CPU oracle as a stand-in producer (this is a
+test of the partition + gather logic in cuda_selection_criteria_amd/distributed.py, which is backend-agnostic).  Rows are
+dealt out the way the product deals them -- interleaved blocks of 128 rows, block b on rank b mod world
+(selhip_ctx_set_row_interleave) -- and the union of the shards must equal the single-rank answer, with no duplicates and
+every record on the rank that owns its row.  The GPU side of the same partition (Selector.set_row_interleave, parts 0..P-1 on
+one device tile the full result and its statistics) is tests/test_gpu_parity.py::test_interleaved_row_blocks_tile_the_pair_space."""
 import os
 import sys
 from pathlib import Path
@@ -33,14 +36,21 @@ def _worker(rank, world, port, out_dir):
         hll, aux, cards = hll[perm], aux[perm], cards[perm]
         r, b = pkg.banding(cfg.m, cfg.tau)
         hi = D.cb_bounds(cards, cfg.tau)
+        BLOCK = 32                                       # small blocks so that 300 rows give both ranks several (the product uses 128)
+        # stand-in for Selector.set_row_interleave(BLOCK, world, rank) + run(): the oracle on the full set, filtered to the rows this rank owns
+        full, st = orc.select(hll, aux, cards, cfg.tau, r, b, use_cb=True, threads=2)
+        mine = full[D.interleave_owner(full["i"], BLOCK, world) == rank]
+        # the partition is a partition of the PAIR SPACE too: per-rank pair counts add up to the oracle's evaluated count
+        pc = D.interleave_pair_counts(len(cards), BLOCK, world, hi, D.first_nonzero(cards))
+        assert int(pc.sum()) == st["evaluated"] and (pc > 0).all(), (pc, st)
+        # the contiguous equal-pair cut (selhost_shard_rows) covers the same space
         bounds = D.shard_rows(len(cards), world, hi, D.first_nonzero(cards))
-        lo, up = int(bounds[rank]), int(bounds[rank + 1])
-        # stand-in for Selector.run(rows=(lo, up)): the oracle on the full set, filtered to this rank's rows
-        full, _ = orc.select(hll, aux, cards, cfg.tau, r, b, use_cb=True, threads=2)
-        mine = full[(full["i"] >= lo) & (full["i"] < up)]
+        assert int(D.pair_counts(len(cards), bounds, hi, D.first_nonzero(cards)).sum()) == st["evaluated"]
         local = np.zeros(len(mine), dtype=PAIR_DTYPE)
         local["i"], local["k"], local["jaccard"] = mine["i"], mine["k"], mine["jacc"]
         gathered = D.gather_pairs(local, dist)
+        key = gathered["i"].astype(np.int64) * len(cards) + gathered["k"]
+        assert len(np.unique(key)) == len(key)
         ok = (len(gathered) == len(full) and np.array_equal(gathered["i"], full["i"]) and np.array_equal(gathered["k"], full["k"])
               and np.array_equal(gathered["jaccard"].view(np.uint64), full["jacc"].view(np.uint64)))
         Path(out_dir, f"rank{rank}.txt").write_text(f"{int(ok)} {len(local)} {len(full)}")

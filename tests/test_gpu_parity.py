@@ -308,6 +308,25 @@ def test_list_overflow_grows_and_repeats(oracle, algo, grouping):
         assert_same_pairs(got, want)
 
 
+@pytest.mark.parametrize("algo", [ALGO_SIG, ALGO_STREAM])
+def test_harder_workload_vs_oracle(oracle, algo):
+    """bench.py's `harder_workload` recipe (pkg.harden: 25 % of the genomes get buckets mod 2, so >= 1 % of ALL pairs pass a
+    band and reach stage 2) at N = 3000, m = 512, tau = 0.8: pairs, Jaccard bits and counters equal the oracle's"""
+    cfg = SynthConfig("hard", 3000, 512, 0.8, 0x5EED0002)
+    hll, aux, cards, _, _ = sorted_set(cfg, oracle)
+    n_deg = pkg.harden(aux)
+    assert 600 < n_deg < 900
+    r, b = pkg.banding(cfg.m, cfg.tau)
+    want, st = oracle.select(hll, aux, cards, cfg.tau, r, b, use_cb=False)
+    assert st["survivors"] > 0.01 * st["evaluated"]          # the point of the recipe
+    with Selector(0) as sel:
+        sel.upload(hll, aux, cards)
+        got = sel.run(cfg.tau, MODE_SMH, r, b, algo=algo)
+        assert_same_pairs(got, want)
+        s = sel.stats()
+        assert s["survivors"] == st["survivors"] and s["evaluated"] == st["evaluated"]
+
+
 def test_edge_cases(oracle):
     cfg = SynthConfig("edge", 130, 128, 0.9, 77, n_sh_lo=5000, n_sh_hi=5000)
     hll, aux, cards, _, _ = sorted_set(cfg, oracle)
