@@ -51,6 +51,8 @@ _vp, _i, _i64, _d, _sz, _cp = C.c_void_p, C.c_int, C.c_int64, C.c_double, C.c_si
 HIP_SYMBOLS = {
     "launch_kernel_smh": (_i, [_vp, _vp, _vp, _vp, _i, _d, _i, _i, _i, _i, _vp, _vp, _i]),
     "launch_kernel_CBsmh": (_i, [_vp, _vp, _vp, _vp, _i, _d, _i, _i, _i, _i, _vp, _vp, _i]),
+    "launch_kernel_smh64": (_i, [_vp, _vp, _vp, _vp, _i64, _d, _i, _i, _i, _i, _vp, _vp, _i]),
+    "launch_kernel_CBsmh64": (_i, [_vp, _vp, _vp, _vp, _i64, _d, _i, _i, _i, _i, _vp, _vp, _i]),
     "selhip_device_count": (_i, []),
     "selhip_ctx_create": (_i, [C.POINTER(_vp), _i]),
     "selhip_ctx_destroy": (None, [_vp]),
@@ -82,7 +84,7 @@ HIP_SYMBOLS = {
     "selhip_ctx_kernel_ms": (_d, [_vp, _cp]),
     "selhip_ctx_kernel_launches": (_d, [_vp, _cp]),
     "selhip_ctx_timing": (_i, [_vp, _i]),
-    "selhip_multi_select": (_i, [_vp, _i, _vp, _vp, _vp, _i64, _i, _i, _i, _i, _i, C.c_float, _i, _i, _i, _vp, _i64, C.POINTER(_i64), C.POINTER(_i64)]),
+    "selhip_multi_select": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i64, _i, _i, _i, _i, _i, C.c_float, _i, _i, _i, _vp, _i64, C.POINTER(_i64), C.POINTER(_i64)]),
     "selhip_ooc_select": (_i, [_i, _vp, _vp, _vp, _vp, _i, _i, _i64, _i, _i, _i, _i, _i, C.c_float, _i, _i, _i64, _i,
                                _vp, _i64, C.POINTER(_i64), C.POINTER(_i64)]),
     "selhip_ctx_set_candidate_begin": (_i, [_vp, _i64]),

@@ -10,7 +10,7 @@
 //   -c <crit>   smh_a (default; the only criterion of the reference's GPU driver, selection_cuda.cpp:64), or hll_a /
 //               hll_an as in the CPU program (src/selection.cpp:122-227: auxiliary HLL p = ctz(aux_bytes), file .hll_<p>)
 //   -t <n>      host threads for loading sketches (selection.cpp:97)
-//   -g <n>      number of GPUs to shard the pair space over (default 1); selected pairs gathered over RCCL/xGMI
+//   -g <n>      number of GPUs to shard the pair space over (default 1; any criterion); selected pairs gathered over RCCL/xGMI
 //   -n          no CB pruning ("smh_a" mode of experiments/src/time_smh.cpp:229-257)
 //   -A <algo>   stage-1 algorithm: auto | stream | sig
 //   -F <0|1>    estimator flavour: 1 = FMA (reference Makefile build on FMA hosts, default), 0 = strict
@@ -115,7 +115,7 @@ int main(int argc, char* argv[]) {
         }
         parts[0].resize((size_t)cnt);
         n_gpus = 1;
-    } else if (n_gpus > 1 && crit == SELHIP_CRIT_SMH_A) {
+    } else if (n_gpus > 1) {
         // one process, one thread + context per device, selected pairs gathered over RCCL/xGMI (host merge if RCCL is
         // unavailable): selhip_multi_select
         std::vector<int> devs((size_t)n_gpus);
@@ -123,7 +123,8 @@ int main(int argc, char* argv[]) {
         int64_t cnt = 0, cap = 1 << 20;
         for (int attempt = 0; attempt < 2; ++attempt) {
             parts[0].resize((size_t)cap);
-            int r = selhip_multi_select(devs.data(), n_gpus, selhost_dataset_hll(ds), aux_ptr, selhost_dataset_cards(ds), n, m_up, 14,
+            int r = selhip_multi_select(devs.data(), n_gpus, selhost_dataset_hll(ds), aux_ptr, selhost_dataset_cards(ds),
+                                        p_aux ? selhost_dataset_aux_hll(ds) : nullptr, (int)p_aux, crit, n, m_up, 14,
                                         mode, algo, fp_mode, threshold, n_rows, n_bands, SELHIP_GATHER_RCCL_OR_HOST,
                                         parts[0].data(), cap, &cnt, nullptr);
             if (r == SELHIP_E_OVERFLOW && attempt == 0) { cap = cnt; continue; }

@@ -92,6 +92,7 @@ struct KernelTimer {
 };
 
 constexpr int kMaxChunks = 8;
+constexpr long long kEnumPairs = 1ll << 26;    // hll_a / hll_an as first criterion: pairs listed per sub-pass (512 MiB of int2)
 
 enum { T_PREP = 0, T_STAGE1, T_HIST, T_SELECT, T_TOTAL, T_SIGBUILD, T_JOIN, T_VERIFY, T_AUX, T_GROUP, T_COUNT };
 const char* kTimerNames[T_COUNT] = {"prep", "stage1", "hist", "select", "total", "sigbuild", "join", "verify", "aux", "group"};
@@ -152,6 +153,7 @@ struct selhip_ctx {
     int join_db = 1;                    // 16-bit join: double-buffered query batches
     int join_bits = 16;                 // signature width of the all-pairs join: 16 (packed, + 32-bit filter) or 32
     int join_q = 1;                     // 16-bit join, query side: 1 = tile staged in LDS, broadcast reads (sigl_join_kernel), 0 = DPP row broadcast (sig16_join_kernel)
+    long long enum_pairs = kEnumPairs;  // hll_a / hll_an as first criterion: pairs listed per sub-pass (test hook "enum_pairs")
     int init_cap = 0;                   // test hook: initial capacity of the survivor / candidate lists (0 = sized from the workload)
     int join_qt = 64;                   // query rows per signature-join block (multiple of 16).  With the segmented appends: cfg3 112 / 114 / 127 us at
                                         // 64 / 96 / 128 rows (finer tiles balance the 1 024 SIMDs better), cfg4 2.12 / 2.10 / 2.07 ms, cfg5 8.31 / 8.16 / 8.20 ms
@@ -336,6 +338,7 @@ hipError_t launch_join(selhip_ctx* c, const StageIO& io, int n_pad, int rb, int 
 template <int ND, bool DB, int WPB>
 hipError_t launch_join16_w(selhip_ctx* c, const StageIO& io, int n_pad, int rb, int re) {
     const int n = (int)c->n;
+    if ((long long)ND * n_pad * 4 >= (1ll << 31)) return hipErrorInvalidValue;          // 32-bit offsets into the band-major signature array
     const int qt = c->join_qt;
     const RowMap rm = row_map(c, rb, re);
     const long long n_tiles_ll = rm.n_tiles(qt);
@@ -364,6 +367,7 @@ hipError_t launch_joinl_w(selhip_ctx* c, const StageIO& io, int n_pad, int rb, i
     const long long n_tiles_ll = rm.n_tiles(qt);
     if (n_tiles_ll > 0x7FFFFFFFll) return hipErrorInvalidValue;
     const int n_tiles = (int)n_tiles_ll;
+    if ((long long)ND * n_pad * 4 >= (1ll << 31)) return hipErrorInvalidValue;          // 32-bit offsets into the band-major signature array
     constexpr int GPB = WPB * T;                                                          // candidate groups per block
     const int group_base = (std::max(rb + 1, (int)c->cand_begin) / kWave / GPB) * GPB;   // candidates k > row_begin, k >= cand_begin
     const int n_groups = (n + kWave - 1) / kWave - group_base;
@@ -684,27 +688,54 @@ int enqueue_pass(selhip_ctx* c) {
         if (use_hash)     HIPCHK(&c->err, launch_stage1_hashjoin(c, io, c->n_rows, c->n_bands, rb, re));
         else if (use_sig) HIPCHK(&c->err, launch_stage1_sig(c, io, c->n_rows, c->n_bands, rb, re));
         else              HIPCHK(&c->err, launch_stage1(c, io, c->n_rows, c->n_bands, rb, re));
-    } else {
-        TimerScope t(c, T_STAGE1);
-        const RowMap rm = row_map(c, rb, re);
-        const long long rows = rm.n_tiles(1);
-        const long long blocks = rows * ((n + kBlock - 1) / kBlock);
-        if (blocks > 0x7FFFFFFFll) { set_err(&c->err, "row range too large"); return SELHIP_E_BADARG; }
-        if (blocks > 0) {
-            hipLaunchKernelGGL(enum_pairs_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, c->stream, n, c->hi.p, pc0,
-                               rm, (int)rows, c->cand.p, (u64)c->cand.cap, io.pc);
-            HIPCHK(&c->err, hipGetLastError());
-        }
     }
     // ---- auxiliary-HLL criterion (hll_a / hll_an): histogram + estimator + test fused, one lane per pair
-    if (crit != SELHIP_CRIT_SMH_A) {
+    if (crit == SELHIP_CRIT_HLL_A_SMH_A) {
+        // two-stage form (BASELINE configs[4]): the auxiliary criterion sees the survivors of the smh_a join
         TimerScope t(c, T_AUX);
-        const selhip_int2_t* list = crit == SELHIP_CRIT_HLL_A_SMH_A ? c->surv.p : c->cand.p;
-        const u64* n_dev = crit == SELHIP_CRIT_HLL_A_SMH_A ? &io.pc->n_survivors : &io.pc->n_aux_in;
-        const u64 cap = crit == SELHIP_CRIT_HLL_A_SMH_A ? (u64)c->surv.cap : (u64)c->cand.cap;
-        const u64 bound = crit == SELHIP_CRIT_HLL_A_SMH_A ? cap : std::min<u64>(cap, (u64)pair_bound(n, rb, re));
-        if (crit == SELHIP_CRIT_HLL_AN) HIPCHK(&c->err, launch_aux_fused<2>(c, list, n_dev, cap, bound, tau, &io.pc->n_final));
-        else                            HIPCHK(&c->err, launch_aux_fused<1>(c, list, n_dev, cap, bound, tau, &io.pc->n_final));
+        HIPCHK(&c->err, launch_aux_fused<1>(c, c->surv.p, &io.pc->n_survivors, (u64)c->surv.cap, (u64)c->surv.cap, tau, &io.pc->n_final));
+        final_list = c->fin.p;
+        final_count = &io.pc->n_final;
+        final_cap = (u64)c->fin.cap;
+    } else if (crit != SELHIP_CRIT_SMH_A) {
+        // hll_a / hll_an as FIRST criterion (selection.cpp:152-173, 206-227): the (CB-pruned) pair space of the rows is listed
+        // explicitly, kEnumPairs pairs at a time -- row sub-ranges in turn on the stream, each listed into the same buffer and
+        // filtered into `fin` before the next one overwrites it (the reference has no limit on N here; round 1 refused
+        // more than 2^28 pairs per call).  Sub-range boundaries fall on whole interleave periods so that row ownership
+        // (RowMap blocks are counted from the range's first row) is the same as for the whole range.
+        const long long period = c->il_parts > 1 ? (long long)c->il_block * c->il_parts : 1;
+        long long sb = rb;
+        while (sb < re) {
+            long long se = sb;
+            long long acc = 0;
+            while (se < re) {
+                const long long step_end = std::min<long long>(re, se + period);
+                const long long add = pair_bound(n, se, step_end);
+                if (se > sb && acc + add > c->enum_pairs) break;
+                acc += add; se = step_end;
+            }
+            if ((u64)acc + 1024 > (u64)c->cand.cap) { set_err(&c->err, "internal: enumeration buffer too small for rows [%lld,%lld)", sb, se); return SELHIP_E_OVERFLOW; }
+            {
+                TimerScope t(c, T_STAGE1);
+                HIPCHK(&c->err, hipMemsetAsync(&io.pc->n_aux_in, 0, sizeof(u64), c->stream));
+                RowMap rm = row_map(c, rb, re);
+                if (c->il_parts <= 1) { rm = row_map(c, (int)sb, (int)se); }
+                else { rm.row_begin = (int)sb; rm.row_end = (int)se; }            // sb - rb is a multiple of the interleave period
+                const long long rows = rm.n_tiles(1);
+                const long long blocks = rows * ((n + kBlock - 1) / kBlock);
+                if (blocks > 0x7FFFFFFFll) { set_err(&c->err, "row range too large"); return SELHIP_E_BADARG; }
+                if (blocks > 0) {
+                    hipLaunchKernelGGL(enum_pairs_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, c->stream, n, c->hi.p, pc0,
+                                       rm, (int)rows, c->cand.p, (u64)c->cand.cap, io.pc);
+                    HIPCHK(&c->err, hipGetLastError());
+                }
+            }
+            TimerScope t(c, T_AUX);
+            const u64 bound = std::min<u64>((u64)c->cand.cap, (u64)acc);
+            if (crit == SELHIP_CRIT_HLL_AN) HIPCHK(&c->err, launch_aux_fused<2>(c, c->cand.p, &io.pc->n_aux_in, (u64)c->cand.cap, bound, tau, &io.pc->n_final));
+            else                            HIPCHK(&c->err, launch_aux_fused<1>(c, c->cand.p, &io.pc->n_aux_in, (u64)c->cand.cap, bound, tau, &io.pc->n_final));
+            sb = se;
+        }
         final_list = c->fin.p;
         final_count = &io.pc->n_final;
         final_cap = (u64)c->fin.cap;
@@ -771,12 +802,12 @@ int ensure_scratch(selhip_ctx* c, size_t surv_cap, size_t res_cap) {
     HIPCHK(&c->err, c->cand.ensure(surv_cap));
     if (c->criterion != SELHIP_CRIT_SMH_A) HIPCHK(&c->err, c->fin.ensure(surv_cap));
     if (c->criterion == SELHIP_CRIT_HLL_A || c->criterion == SELHIP_CRIT_HLL_AN) {
-        // the explicit pair space of the row range is materialised (8 B per pair)
-        const long long bound = pair_bound(c->n, c->row_begin, c->row_end);
-        if (bound > (1ll << 28)) {
-            set_err(&c->err, "hll_a/hll_an as first criterion enumerates %lld pairs for this row range; pass sub-ranges of rows (<= 2^28 pairs each)", bound);
-            return SELHIP_E_BADARG;
-        }
+        // the explicit pair space is materialised kEnumPairs pairs at a time (8 B per pair); one interleave period of rows is the
+        // smallest unit, so the buffer holds at least that
+        const long long period = c->il_parts > 1 ? (long long)c->il_block * c->il_parts : 1;
+        long long unit = 0;
+        for (long long s = c->row_begin; s < c->row_end; s += period) unit = std::max(unit, pair_bound(c->n, s, std::min<long long>(c->row_end, s + period)));
+        const long long bound = std::min(pair_bound(c->n, c->row_begin, c->row_end), std::max(c->enum_pairs, unit));
         HIPCHK(&c->err, c->cand.ensure((size_t)bound + 1024));
     }
     {
@@ -918,6 +949,11 @@ int selhip_ctx_set_param(selhip_ctx* c, const char* name, int value) {
     }
     if (!std::strcmp(name, "join_db")) { c->join_db = value != 0; return SELHIP_OK; }
     if (!std::strcmp(name, "join_q")) { c->join_q = value != 0; return SELHIP_OK; }
+    if (!std::strcmp(name, "enum_pairs")) {
+        if (value < 1) { set_err(&c->err, "enum_pairs must be >= 1"); return SELHIP_E_BADARG; }
+        c->enum_pairs = value;
+        return SELHIP_OK;
+    }
     if (!std::strcmp(name, "init_cap")) {
         if (value < 0) { set_err(&c->err, "init_cap must be >= 0"); return SELHIP_E_BADARG; }
         c->init_cap = value;
@@ -1314,17 +1350,19 @@ struct CompatWs {
     DevBuf<selhip_int2_t> surv;
     DevBuf<uint32_t> counts;
     DevBuf<u64> surv_count;
+    selhip_ctx* ctx[64] = {};          // implicit-enumeration path: one cached context per device (process lifetime)
 };
 CompatWs g_ws;
+constexpr long long kCompatChunk = 1ll << 20;      // explicit pair lists are processed this many pairs at a time (256 MiB of histograms)
 
 // select for the drop-in launchers: the reference signature carries no genome count, so the truncated
 // cardinalities are taken on the fly from cards[rank]; output record = struct Result {x, y, (float)J}.
-template <bool FMA>
+template <bool FMA, typename CountT>
 __global__ __launch_bounds__(kWave)
 void compat_select_kernel(const uint32_t* __restrict__ counts, const u64* __restrict__ n_dev, u64 cap, int p,
                           double relerr_scaled, const selhip_int2_t* __restrict__ pairs,
                           const double* __restrict__ cards, double tau,
-                          selhip_result_t* __restrict__ out, int* __restrict__ out_count) {
+                          selhip_result_t* __restrict__ out, CountT* __restrict__ out_count) {
     __shared__ uint32_t lds[64 * 65];
     const int lane = threadIdx.x;
     u64 n = *n_dev;
@@ -1344,40 +1382,77 @@ void compat_select_kernel(const uint32_t* __restrict__ counts, const u64* __rest
             const double e1 = (double)selhip::trunc_card(cards[pr.x]), e2 = (double)selhip::trunc_card(cards[pr.y]);
             const double jacc = (e1 + e2 - t) / t;                           // selection.cpp:287
             if (jacc >= tau) {                                               // selection.cpp:288
-                int idx = atomicAdd(out_count, 1);
+                const CountT idx = atomicAdd(out_count, (CountT)1);
                 out[idx].x = pr.x; out[idx].y = pr.y; out[idx].sim = (float)jacc;
             }
         }
     }
 }
 
+// implicit enumeration: the context's result records {i, k, double J} -> struct Result {x, y, (float)J}, and the count
+template <typename CountT>
+__global__ __launch_bounds__(kBlock)
+void compat_convert_kernel(const selhip_pair_t* __restrict__ res, u64 n, selhip_result_t* __restrict__ out, CountT* __restrict__ out_count) {
+    for (u64 j = (u64)blockIdx.x * kBlock + threadIdx.x; j < n; j += (u64)gridDim.x * kBlock) {
+        const selhip_pair_t r = res[j];
+        out[j].x = r.i; out[j].y = r.k; out[j].sim = (float)r.jaccard;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) *out_count = (CountT)n;
+}
+
+template <typename CountT>
 int compat_launch(bool use_cb, const uint8_t* main_sketches, const uint64_t* aux, const double* cards,
-                  const selhip_int2_t* pairs, int total_pairs, double tau, int m_aux, int m_hll,
-                  int n_rows, int n_bands, selhip_result_t* out, int* out_count) {
+                  const selhip_int2_t* pairs, long long total_pairs, double tau, int m_aux, int m_hll,
+                  int n_rows, int n_bands, selhip_result_t* out, CountT* out_count) {
     if (!main_sketches || !aux || !cards || !out || !out_count) { set_err(nullptr, "null pointer argument"); return SELHIP_E_BADARG; }
     if (total_pairs < 0 || m_aux <= 0 || !is_pow2(m_hll) || m_hll < 16) { set_err(nullptr, "bad sizes"); return SELHIP_E_BADARG; }
     if (n_rows <= 0 || n_bands <= 0 || (long long)n_rows * n_bands != m_aux) { set_err(nullptr, "n_rows*n_bands != m_aux"); return SELHIP_E_BADARG; }
-    if (!pairs && total_pairs > 0) { set_err(nullptr, "pairs == NULL (use the selhip_ctx_* API for implicit all-pairs enumeration)"); return SELHIP_E_BADARG; }
     hipStream_t st = nullptr;                                        // default stream, like the reference
-    HIPCHK(nullptr, hipMemsetAsync(out_count, 0, sizeof(int), st));  // selection_kernels.cu:137,166
+    HIPCHK(nullptr, hipMemsetAsync(out_count, 0, sizeof(CountT), st));  // selection_kernels.cu:137,166
     if (total_pairs == 0) return SELHIP_OK;
-    std::lock_guard<std::mutex> lk(g_ws.mu);
-    HIPCHK(nullptr, g_ws.surv.ensure((size_t)total_pairs));
-    HIPCHK(nullptr, g_ws.counts.ensure((size_t)total_pairs * 64));
-    HIPCHK(nullptr, g_ws.surv_count.ensure(1));
-    HIPCHK(nullptr, hipMemsetAsync(g_ws.surv_count.p, 0, sizeof(u64), st));
-    hipLaunchKernelGGL(pairlist_smh_kernel, dim3((unsigned)((total_pairs + kBlock - 1) / kBlock)), dim3(kBlock), 0, st,
-                       (const u64*)aux, m_aux, n_rows, n_bands, pairs, (long long)total_pairs, cards, tau, 1, use_cb ? 1 : 0,
-                       (uint8_t*)nullptr, g_ws.surv.p, (u64)g_ws.surv.cap, g_ws.surv_count.p);
-    HIPCHK(nullptr, hipGetLastError());
     const int p = ilog2(m_hll);
-    hipLaunchKernelGGL(hll_union_hist_kernel, dim3(2048), dim3(kBlock), 0, st, main_sketches, p, g_ws.surv.p,
-                       g_ws.surv_count.p, (u64)0, (u64)g_ws.surv.cap, g_ws.counts.p);
-    HIPCHK(nullptr, hipGetLastError());
-    hipLaunchKernelGGL((compat_select_kernel<true>), dim3(4096), dim3(kWave), 0, st,
-                       g_ws.counts.p, g_ws.surv_count.p, (u64)g_ws.surv.cap, p, relerr_scaled_for(p), g_ws.surv.p,
-                       cards, tau, out, out_count);
-    HIPCHK(nullptr, hipGetLastError());
+    std::lock_guard<std::mutex> lk(g_ws.mu);
+    if (!pairs) {
+        // pairs == NULL: the list is the implicit triangle i < k < n of the reference driver (selection_cuda.cpp:146-150), which is
+        // never materialised -- total_pairs must be n(n-1)/2 and fixes n.  Runs through a cached context attached to the caller's
+        // device arrays (all-pairs signature join + stage 2); this variant waits for the pass before it returns.
+        const long long nn = (long long)((1.0 + std::sqrt(1.0 + 8.0 * (double)total_pairs)) / 2.0);
+        long long n = nn;
+        for (long long c = nn - 1; c <= nn + 1; ++c) if (c >= 2 && c * (c - 1) / 2 == total_pairs) n = c;
+        if (n < 2 || n * (n - 1) / 2 != total_pairs) { set_err(nullptr, "pairs == NULL needs total_pairs = n(n-1)/2 (the whole triangle); got %lld", total_pairs); return SELHIP_E_BADARG; }
+        int dev = 0;
+        HIPCHK(nullptr, hipGetDevice(&dev));
+        if (dev < 0 || dev >= 64) { set_err(nullptr, "device index out of range"); return SELHIP_E_BADARG; }
+        if (!g_ws.ctx[dev]) { int r = selhip_ctx_create(&g_ws.ctx[dev], dev); if (r) return r; }
+        selhip_ctx* c = g_ws.ctx[dev];
+        int r = selhip_ctx_attach(c, main_sketches, aux, cards, n, m_aux, p);
+        if (!r) r = selhip_ctx_run(c, use_cb ? SELHIP_MODE_CB_SMH : SELHIP_MODE_SMH, SELHIP_ALGO_AUTO, (float)tau, n_rows, n_bands, 0, n);
+        if (r) { set_err(nullptr, "%s", selhip_last_error(c)); return r; }
+        const u64 cnt = c->last.n_results;
+        if (sizeof(CountT) == 4 && cnt > 0x7FFFFFFFull) { set_err(nullptr, "more than 2^31 selected pairs: use the 64-bit launcher"); return SELHIP_E_OVERFLOW; }
+        hipLaunchKernelGGL((compat_convert_kernel<CountT>), dim3(grid_for(cnt, kBlock, 4096)), dim3(kBlock), 0, c->stream, c->results.p, cnt, out, out_count);
+        HIPCHK(nullptr, hipGetLastError());
+        return SELHIP_OK;
+    }
+    const long long chunk = std::min(total_pairs, kCompatChunk);
+    HIPCHK(nullptr, g_ws.surv.ensure((size_t)chunk));
+    HIPCHK(nullptr, g_ws.counts.ensure((size_t)chunk * 64));
+    HIPCHK(nullptr, g_ws.surv_count.ensure(1));
+    for (long long off = 0; off < total_pairs; off += chunk) {
+        const long long len = std::min(chunk, total_pairs - off);
+        HIPCHK(nullptr, hipMemsetAsync(g_ws.surv_count.p, 0, sizeof(u64), st));
+        hipLaunchKernelGGL(pairlist_smh_kernel, dim3((unsigned)((len + kBlock - 1) / kBlock)), dim3(kBlock), 0, st,
+                           (const u64*)aux, m_aux, n_rows, n_bands, pairs + off, len, cards, tau, 1, use_cb ? 1 : 0,
+                           (uint8_t*)nullptr, g_ws.surv.p, (u64)g_ws.surv.cap, g_ws.surv_count.p);
+        HIPCHK(nullptr, hipGetLastError());
+        hipLaunchKernelGGL(hll_union_hist_kernel, dim3(2048), dim3(kBlock), 0, st, main_sketches, p, g_ws.surv.p,
+                           g_ws.surv_count.p, (u64)0, (u64)g_ws.surv.cap, g_ws.counts.p);
+        HIPCHK(nullptr, hipGetLastError());
+        hipLaunchKernelGGL((compat_select_kernel<true, CountT>), dim3(4096), dim3(kWave), 0, st,
+                           g_ws.counts.p, g_ws.surv_count.p, (u64)g_ws.surv.cap, p, relerr_scaled_for(p), g_ws.surv.p,
+                           cards, tau, out, out_count);
+        HIPCHK(nullptr, hipGetLastError());
+    }
     return SELHIP_OK;
 }
 }  // namespace
@@ -1389,7 +1464,7 @@ int launch_kernel_smh(const uint8_t* main_sketches, const uint64_t* aux_sketches
                       int m_aux, int m_hll, int n_rows, int n_bands,
                       selhip_result_t* out, int* out_count, int blockSize) {
     (void)blockSize;
-    return compat_launch(false, main_sketches, aux_sketches, cards, pairs, total_pairs, tau, m_aux, m_hll, n_rows, n_bands, out, out_count);
+    return compat_launch<int>(false, main_sketches, aux_sketches, cards, pairs, total_pairs, tau, m_aux, m_hll, n_rows, n_bands, out, out_count);
 }
 
 int launch_kernel_CBsmh(const uint8_t* main_sketches, const uint64_t* aux_sketches, const double* cards,
@@ -1397,7 +1472,27 @@ int launch_kernel_CBsmh(const uint8_t* main_sketches, const uint64_t* aux_sketch
                         int m_aux, int m_hll, int n_rows, int n_bands,
                         selhip_result_t* out, int* out_count, int blockSize) {
     (void)blockSize;
-    return compat_launch(true, main_sketches, aux_sketches, cards, pairs, total_pairs, tau, m_aux, m_hll, n_rows, n_bands, out, out_count);
+    return compat_launch<int>(true, main_sketches, aux_sketches, cards, pairs, total_pairs, tau, m_aux, m_hll, n_rows, n_bands, out, out_count);
+}
+
+// 64-bit variants: the reference's `int total_pairs` / `int idx` (selection_kernels.cu:29-30) overflow beyond 2^31 pairs
+// (N > 65 536 genomes); same parameter lists with int64_t total_pairs and a 64-bit *out_count.
+int launch_kernel_smh64(const uint8_t* main_sketches, const uint64_t* aux_sketches, const double* cards,
+                        const selhip_int2_t* pairs, int64_t total_pairs, double tau,
+                        int m_aux, int m_hll, int n_rows, int n_bands,
+                        selhip_result_t* out, int64_t* out_count, int blockSize) {
+    (void)blockSize;
+    return compat_launch<unsigned long long>(false, main_sketches, aux_sketches, cards, pairs, total_pairs, tau, m_aux, m_hll, n_rows, n_bands, out,
+                                             reinterpret_cast<unsigned long long*>(out_count));
+}
+
+int launch_kernel_CBsmh64(const uint8_t* main_sketches, const uint64_t* aux_sketches, const double* cards,
+                          const selhip_int2_t* pairs, int64_t total_pairs, double tau,
+                          int m_aux, int m_hll, int n_rows, int n_bands,
+                          selhip_result_t* out, int64_t* out_count, int blockSize) {
+    (void)blockSize;
+    return compat_launch<unsigned long long>(true, main_sketches, aux_sketches, cards, pairs, total_pairs, tau, m_aux, m_hll, n_rows, n_bands, out,
+                                             reinterpret_cast<unsigned long long*>(out_count));
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1554,9 +1649,12 @@ int selhip_ooc_select(int device, const uint8_t* h_hll, const uint64_t* h_aux, c
 
 int selhip_multi_select(const int* devices, int n_devices,
                         const uint8_t* h_hll, const uint64_t* h_aux, const double* h_cards,
+                        const uint8_t* h_aux_hll, int p_aux, int criterion,
                         int64_t n, int m, int p_hll, int mode, int algo, int fp_mode, float tau_f, int n_rows, int n_bands,
                         int gather, selhip_pair_t* h_out, int64_t cap, int64_t* count_out, int64_t stats_out[4]) {
     if (!devices || n_devices < 1 || n_devices > 64 || !count_out || cap < 0 || (cap && !h_out)) { set_err(nullptr, "bad argument"); return SELHIP_E_BADARG; }
+    if (criterion < SELHIP_CRIT_SMH_A || criterion > SELHIP_CRIT_HLL_A_SMH_A) { set_err(nullptr, "bad criterion %d", criterion); return SELHIP_E_BADARG; }
+    if (criterion != SELHIP_CRIT_SMH_A && n > 0 && (!h_aux_hll || p_aux < 4 || p_aux > 16)) { set_err(nullptr, "criterion %d needs auxiliary HLL sketches (h_aux_hll, p_aux in [4,16])", criterion); return SELHIP_E_BADARG; }
     if (gather < SELHIP_GATHER_HOST || gather > SELHIP_GATHER_RCCL_OR_HOST) { set_err(nullptr, "bad gather mode"); return SELHIP_E_BADARG; }
     *count_out = 0;
     const int G = n_devices;
@@ -1589,6 +1687,8 @@ int selhip_multi_select(const int* devices, int n_devices,
             selhip_ctx* c = ctxs[(size_t)g];
             r = selhip_ctx_set_fp_mode(c, fp_mode);
             if (!r) r = selhip_ctx_upload(c, h_hll, h_aux, h_cards, n, m, p_hll);
+            if (!r && criterion != SELHIP_CRIT_SMH_A && n > 0) r = selhip_ctx_upload_aux_hll(c, h_aux_hll, p_aux);
+            if (!r) r = selhip_ctx_set_criterion(c, criterion);
             // interleaved row blocks: every device gets the same share of pairs and of survivors
             if (!r) r = selhip_ctx_set_row_interleave(c, 128, G, g);
             if (!r) r = selhip_ctx_run(c, mode, algo, tau_f, n_rows, n_bands, 0, n);

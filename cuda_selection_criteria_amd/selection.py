@@ -317,9 +317,10 @@ def select_from_filelist(list_file: str, tau: float, aux_bytes: int, mode: int =
 
 def multi_select(devices: Sequence[int], hll: np.ndarray, aux: np.ndarray, cards: np.ndarray, tau: float,
                  mode: int = MODE_CB_SMH, n_rows: Optional[int] = None, n_bands: Optional[int] = None, algo: int = ALGO_AUTO,
-                 fp_mode: int = FP_FMA, gather: int = 2):
-    """selhip_multi_select: one process, one context per listed device, equal-pair row shards, RCCL (or host) gather.
-    gather: 0 host merge, 1 RCCL required, 2 RCCL if available.  Returns (pairs sorted by (i,k), stats dict)."""
+                 fp_mode: int = FP_FMA, gather: int = 2, criterion: int = 0, aux_hll: Optional[np.ndarray] = None, p_aux: int = 0):
+    """selhip_multi_select: one process, one context per listed device, interleaved row blocks, RCCL (or host) gather.
+    gather: 0 host merge, 1 RCCL required, 2 RCCL if available; criterion / aux_hll / p_aux as for Selector (hll_a, hll_an,
+    the two-stage criterion of BASELINE configs[4]).  Returns (pairs sorted by (i,k), stats dict)."""
     lib = hip_lib()
     hll = np.ascontiguousarray(hll, dtype=np.uint8)
     aux = np.ascontiguousarray(aux, dtype=np.uint64)
@@ -328,12 +329,14 @@ def multi_select(devices: Sequence[int], hll: np.ndarray, aux: np.ndarray, cards
     if n_rows is None or n_bands is None:
         n_rows, n_bands = banding(m, tau)
     devs = (C.c_int * len(devices))(*devices)
+    ah = np.ascontiguousarray(aux_hll, dtype=np.uint8) if aux_hll is not None and criterion != 0 else None
     cap = 1 << 16
     while True:
         out = np.zeros(cap, dtype=PAIR_DTYPE)
         cnt = C.c_int64()
         st = (C.c_int64 * 4)()
-        rc = lib.selhip_multi_select(devs, len(devices), hll.ctypes.data, aux.ctypes.data, cards.ctypes.data, n, m, 14, mode, algo,
+        rc = lib.selhip_multi_select(devs, len(devices), hll.ctypes.data, aux.ctypes.data, cards.ctypes.data,
+                                     ah.ctypes.data if ah is not None else None, p_aux, criterion, n, m, 14, mode, algo,
                                      fp_mode, np.float32(tau), n_rows, n_bands, gather, out.ctypes.data, cap, C.byref(cnt), st)
         if rc == -3:
             cap = int(cnt.value)

@@ -80,13 +80,16 @@ typedef struct { int32_t i, k; double jaccard; } selhip_pair_t;
  *    (CUDA int2 -> selhip_int2_t, Result -> selhip_result_t, void -> int status).
  *    All pointers are device pointers; out must hold total_pairs records (reference contract,
  *    selection_cuda.cpp:164); *out_count is zeroed by the launcher (selection_kernels.cu:137,166).
- *    pairs must be non-NULL when total_pairs > 0 (implicit all-pairs enumeration, which never
- *    materialises the 8 B/pair list, is what the selhip_ctx_* API below is for).
+ *    pairs == NULL selects the IMPLICIT triangle i < k < n of the reference driver (selection_cuda.cpp:146-150) without
+ *    materialising the 8 B/pair list: total_pairs must then be n(n-1)/2, which fixes n; cards must be ascending (the
+ *    driver's order); this variant runs the all-pairs path of the context API and returns after the pass.
+ *    With an explicit list the launchers are asynchronous on the null stream, like the reference.
  *    m_aux is the number of u64 buckets per sketch, m_hll the number of HLL registers (16384).
  *    launch_kernel_smh evaluates every listed pair; launch_kernel_CBsmh additionally applies CB
  *    (the reference kernel of that name does not, selection_kernels.cu:63-117 -- documented defect).
- *    Asynchronous on the null stream, like the reference; blockSize is accepted and ignored
- *    (the kernels choose their own wave64 geometry).
+ *    blockSize is accepted and ignored (the kernels choose their own wave64 geometry).
+ *    launch_kernel_smh64 / launch_kernel_CBsmh64: the same with int64_t total_pairs and a 64-bit *out_count -- the
+ *    reference's `int total_pairs` / `int idx` (selection_kernels.cu:29-30) overflow beyond 2^31 pairs (n > 65 536).
  * --------------------------------------------------------------------------------------------------- */
 int launch_kernel_smh(const uint8_t* main_sketches, const uint64_t* aux_sketches, const double* cards,
                       const selhip_int2_t* pairs, int total_pairs, double tau,
@@ -96,6 +99,14 @@ int launch_kernel_CBsmh(const uint8_t* main_sketches, const uint64_t* aux_sketch
                         const selhip_int2_t* pairs, int total_pairs, double tau,
                         int m_aux, int m_hll, int n_rows, int n_bands,
                         selhip_result_t* out, int* out_count, int blockSize);
+int launch_kernel_smh64(const uint8_t* main_sketches, const uint64_t* aux_sketches, const double* cards,
+                        const selhip_int2_t* pairs, int64_t total_pairs, double tau,
+                        int m_aux, int m_hll, int n_rows, int n_bands,
+                        selhip_result_t* out, int64_t* out_count, int blockSize);
+int launch_kernel_CBsmh64(const uint8_t* main_sketches, const uint64_t* aux_sketches, const double* cards,
+                          const selhip_int2_t* pairs, int64_t total_pairs, double tau,
+                          int m_aux, int m_hll, int n_rows, int n_bands,
+                          selhip_result_t* out, int64_t* out_count, int blockSize);
 
 /* ---------------------------------------------------------------------------------------------------
  * 2. Context API: owns the derived device buffers (truncated cards, CB bounds, band signatures,
@@ -217,13 +228,17 @@ int    selhip_ctx_timing(selhip_ctx* ctx, int enable);
  *     device; the pair space is cut into equal-pair row ranges, every device gets a full replica of the (host)
  *     sketches, and the selected-pair lists are gathered -- over RCCL/xGMI (ncclAllGather of framed record buffers on
  *     communicators from ncclCommInitAll; librccl is dlopen'ed on first use) or through the host.
- *     criterion smh_a.  h_out receives min(count, cap) records sorted by (i,k); stats_out (optional) as selhip_ctx_stats.
+ *     Any criterion (SELHIP_CRIT_*): h_aux_hll / p_aux carry the auxiliary HLL sketches of hll_a, hll_an and the two-stage
+ *     criterion of BASELINE configs[4] (NULL / 0 for smh_a).  Rows are dealt to the devices in interleaved blocks of 128
+ *     (selhip_ctx_set_row_interleave).  h_out receives min(count, cap) records sorted by (i,k); stats_out (optional) as
+ *     selhip_ctx_stats.
  * --------------------------------------------------------------------------------------------------- */
 #define SELHIP_GATHER_HOST           0   /* each device's list is fetched and merged on the host              */
 #define SELHIP_GATHER_RCCL           1   /* RCCL all_gather; an error if RCCL cannot be initialised           */
 #define SELHIP_GATHER_RCCL_OR_HOST   2   /* RCCL if it initialises, host merge otherwise (note in last_error) */
 int selhip_multi_select(const int* devices, int n_devices,
                         const uint8_t* h_hll, const uint64_t* h_aux, const double* h_cards,
+                        const uint8_t* h_aux_hll, int p_aux, int criterion,
                         int64_t n_genomes, int m, int p_hll, int mode, int algo, int fp_mode, float tau_f, int n_rows, int n_bands,
                         int gather, selhip_pair_t* h_out, int64_t cap, int64_t* count_out, int64_t stats_out[4]);
 

@@ -78,30 +78,61 @@ def test_config4_scale_properties():
         assert np.array_equal(hj, whole)
 
 
-def test_config5_two_stage_properties(oracle):
-    """hll_a (p=8) prefilter + smh_a m=1024 (configs[4]) at 20 000 genomes: two-stage == smh_a result filtered by
-    hll_a, checked pair by pair with the oracle's hll_a on the smh_a survivors"""
-    cfg = pkg.SYNTH_CONFIGS["cfg5"].scaled(20_000)
-    hll_t, aux_t, cards_t, _, aux_hll_t = pkg.synth_device(cfg)
+def test_config5_full_size_properties(oracle):
+    """BASELINE configs[4] at ITS size: 100 000 genomes, hll_a (p=8) prefilter + smh_a m=1024, tau=0.9 (5.0e9 pairs -- beyond
+    the oracle's reach in a test, so: properties, and the oracle pair by pair on a sampled band of rows).
+      * smh_a alone: in-cluster pairs only (most of them), Jaccard >= tau, sorted, unique;
+      * two-stage == the smh_a result filtered by the oracle's hll_a, checked pair by pair for the rows [40 000, 44 000);
+        outside the band: a subset of the smh_a result;
+      * the sort-based join gives the same two-stage result for the whole space;
+      * the 8 interleaved row-block parts of the multi-GPU partition tile the result and the evaluated-pair count."""
+    cfg = pkg.SYNTH_CONFIGS["cfg5"]
+    n = cfg.n_genomes
+    assert n == 100_000 and cfg.m == 1024 and cfg.p_aux == 8
+    hll_t, aux_t, cards_t, perm, aux_hll_t = pkg.synth_device(cfg)
     r, b = pkg.banding(cfg.m, cfg.tau)
+    assert (r, b) == (16, 64)
     with Selector(0) as sel:
         sel.attach(hll_t, aux_t, cards_t)
         sel.attach_aux_hll(aux_hll_t, cfg.p_aux)
         smh = sel.run(cfg.tau, MODE_CB_SMH, r, b)
+        st_smh = sel.stats()
+        cluster = perm // cfg.cluster_size
+        # in-cluster pairs only; at tau = 0.9 those with two large private sets (expected Jaccard 0.83) fall below the threshold
+        assert (cluster[smh["i"]] == cluster[smh["k"]]).all() and 0.5 * (n // cfg.cluster_size) * 45 < len(smh) < (n // cfg.cluster_size) * 45
+        assert (smh["jaccard"] >= np.float32(cfg.tau)).all() and (smh["i"] < smh["k"]).all()
+        key = smh["i"].astype(np.int64) * n + smh["k"]
+        assert (np.diff(key) > 0).all()
         sel.set_criterion(pkg.CRIT_HLL_A_SMH_A)
         two = sel.run(cfg.tau, MODE_CB_SMH, r, b)
         st = sel.stats()
+        assert st["evaluated"] == st_smh["evaluated"] and sel.last_attempts() == 1
+        hj = sel.run(cfg.tau, MODE_CB_SMH, r, b, algo=ALGO_HASHJOIN)
+        assert np.array_equal(hj, two)
+        parts, ev = [], 0
+        for part in range(8):
+            sel.set_row_interleave(128, 8, part)
+            parts.append(sel.run(cfg.tau, MODE_CB_SMH, r, b))
+            ev += sel.stats()["evaluated"]
+        sel.set_row_interleave(0, 1, 0)
+        allp = np.concatenate(parts)
+        assert np.array_equal(allp[np.lexsort((allp["k"], allp["i"]))], two) and ev == st["evaluated"]
+        sizes = np.array([len(p) for p in parts])
+        assert sizes.max() < 1.1 * sizes.mean()                                            # the interleave balances stage 2 too
+    key2 = two["i"].astype(np.int64) * n + two["k"]
+    assert np.isin(key2, key).all() and 0 < len(two) <= len(smh)
+    # the oracle's hll_a, pair by pair, on the band
+    lo, hi = 40_000, 44_000
     cards = cards_t.cpu().numpy()
     ah = aux_hll_t.cpu().numpy()
     e = cards.astype(np.uint64)
-    keep = []
     lib = oracle.lib
     import ctypes as C
     lib.orc_hll_a_from_union.argtypes = [C.c_double, C.c_size_t, C.c_size_t, C.c_double, C.c_int, C.c_float]
     tau64 = float(np.float32(cfg.tau))
-    for rec in smh:
-        u = oracle.union_size(ah[rec["i"]], ah[rec["k"]], cfg.p_aux)
-        keep.append(bool(lib.orc_hll_a_from_union(tau64, int(e[rec["i"]]), int(e[rec["k"]]), u, cfg.p_aux, C.c_float(1.96))))
-    want = smh[np.array(keep, dtype=bool)]
-    assert np.array_equal(two, want)
-    assert 0 < len(two) <= len(smh) and st["survivors"] >= len(two)
+    band = smh[(smh["i"] >= lo) & (smh["i"] < hi)]
+    assert len(band) > 10_000
+    keep = [bool(lib.orc_hll_a_from_union(tau64, int(e[rec["i"]]), int(e[rec["k"]]),
+                                          oracle.union_size(ah[rec["i"]], ah[rec["k"]], cfg.p_aux), cfg.p_aux, C.c_float(1.96))) for rec in band]
+    want = band[np.array(keep, dtype=bool)]
+    assert np.array_equal(two[(two["i"] >= lo) & (two["i"] < hi)], want)

@@ -327,6 +327,37 @@ def test_harder_workload_vs_oracle(oracle, algo):
         assert s["survivors"] == st["survivors"] and s["evaluated"] == st["evaluated"]
 
 
+@pytest.mark.parametrize("crit", [pkg.CRIT_HLL_A, pkg.CRIT_HLL_AN])
+def test_aux_first_criterion_enumerates_in_sub_passes(oracle, crit):
+    """hll_a / hll_an as FIRST criterion list the pair space explicitly; more pairs than one list holds are taken in row
+    sub-ranges on the stream ("enum_pairs" shrinks the list for the test; the reference's CPU loop, selection.cpp:152-227, has no
+    size limit, and round 1 refused more than 2^28 pairs).  Contiguous rows and interleaved row blocks, vs the oracle."""
+    cfg = SynthConfig("enum", 700, 128, 0.9, 0x31, p_aux=8, mode=1, n_sh_lo=3000, n_sh_hi=40000)
+    hll, aux, cards, _, ah = sorted_set(cfg, oracle)
+    r, b = pkg.banding(cfg.m, cfg.tau)
+    for use_cb in (True, False):
+        want, st = oracle.select(hll, aux, cards, cfg.tau, r, b, use_cb=use_cb, criterion=crit, aux_hll=ah, p_aux=8)
+        mode = MODE_CB_SMH if use_cb else MODE_SMH
+        with Selector(0) as sel:
+            sel.upload(hll, aux, cards)
+            sel.upload_aux_hll(ah, 8)
+            sel.set_criterion(crit)
+            for budget in (1 << 26, 20000, 1500, 1):
+                sel.set_param("enum_pairs", budget)
+                assert_same_pairs(sel.run(cfg.tau, mode, r, b), want)
+                assert sel.stats()["evaluated"] == st["evaluated"]
+                assert_same_pairs(sel.run(cfg.tau, mode, r, b, rows=(100, 555)), want[(want["i"] >= 100) & (want["i"] < 555)])
+            sel.set_param("enum_pairs", 3000)
+            parts = []
+            for part in range(3):
+                sel.set_row_interleave(32, 3, part)
+                parts.append(sel.run(cfg.tau, mode, r, b))
+            sel.set_row_interleave(0, 1, 0)
+            allp = np.concatenate(parts)
+            allp = allp[np.lexsort((allp["k"], allp["i"]))]
+            assert_same_pairs(allp, want)
+
+
 def test_edge_cases(oracle):
     cfg = SynthConfig("edge", 130, 128, 0.9, 77, n_sh_lo=5000, n_sh_hi=5000)
     hll, aux, cards, _, _ = sorted_set(cfg, oracle)
@@ -506,6 +537,25 @@ def test_drop_in_launchers(oracle):
         want, _ = oracle.select(hll, aux, cards, cfg.tau, r, b, use_cb=use_cb)
         exp = [(int(w["i"]), int(w["k"]), np.float32(w["jacc"])) for w in want]
         assert got == exp
+    # pairs == NULL: the implicit triangle (never materialised), total_pairs = n(n-1)/2; and the 64-bit launchers, with the
+    # explicit list (more pairs than one internal chunk would be > 2^20 -- here the list is 179 700 pairs) and without it
+    d_cnt64 = torch.full((1,), -1, dtype=torch.int64, device=dev)
+    for fn, use_cb, cnt_t, pp in ((lib.launch_kernel_smh, False, d_cnt, None), (lib.launch_kernel_CBsmh, True, d_cnt, None),
+                                  (lib.launch_kernel_smh64, False, d_cnt64, None), (lib.launch_kernel_CBsmh64, True, d_cnt64, None),
+                                  (lib.launch_kernel_smh64, False, d_cnt64, d_pairs.data_ptr()), (lib.launch_kernel_CBsmh64, True, d_cnt64, d_pairs.data_ptr())):
+        d_out.zero_()
+        rc = fn(d_hll.data_ptr(), d_aux.data_ptr(), d_cards.data_ptr(), pp, total, float(tau),
+                cfg.m, 16384, r, b, d_out.data_ptr(), cnt_t.data_ptr(), 256)
+        assert rc == 0, lib.selhip_last_error(None)
+        torch.cuda.synchronize()
+        cnt = int(cnt_t.item())
+        rec = d_out[:cnt].cpu().numpy()
+        got = sorted((int(x), int(y), np.int32(s).view(np.float32)) for x, y, s in rec)
+        want, _ = oracle.select(hll, aux, cards, cfg.tau, r, b, use_cb=use_cb)
+        assert got == [(int(w["i"]), int(w["k"]), np.float32(w["jacc"])) for w in want]
+    # pairs == NULL with a total that is not a whole triangle is refused
+    assert lib.launch_kernel_smh(d_hll.data_ptr(), d_aux.data_ptr(), d_cards.data_ptr(), None, total - 1, float(tau), cfg.m, 16384, r, b,
+                                 d_out.data_ptr(), d_cnt.data_ptr(), 256) < 0
     # error behaviour: status codes instead of the reference's silent void
     assert lib.launch_kernel_smh(None, d_aux.data_ptr(), d_cards.data_ptr(), d_pairs.data_ptr(), total, 0.9, cfg.m, 16384, r, b,
                                  d_out.data_ptr(), d_cnt.data_ptr(), 256) < 0
@@ -680,6 +730,19 @@ def test_multi_device_entry_and_rccl_gather(oracle):
         got, s = multi_select(devices, hll, aux, cards, cfg.tau, MODE_CB_SMH, r, b, gather=gather)
         assert_same_pairs(got, want)
         assert s["evaluated"] == st["evaluated"] and s["survivors"] == st["survivors"], (devices, gather, s, st)
+    # every criterion goes through the device-list entry (round 1: smh_a only): hll_a, hll_an, and the two-stage criterion of
+    # BASELINE configs[4], against the oracle; three contexts on the one card, host merge
+    cfgx = SynthConfig("multi-aux", 500, 256, 0.9, 0x77, p_aux=8)
+    hllx, auxx, cardsx, _, ahx = sorted_set(cfgx, oracle)
+    rx, bx = pkg.banding(cfgx.m, cfgx.tau)
+    for crit in (pkg.CRIT_HLL_A, pkg.CRIT_HLL_AN, pkg.CRIT_HLL_A_SMH_A):
+        want_c, st_c = oracle.select(hllx, auxx, cardsx, cfgx.tau, rx, bx, criterion=crit, aux_hll=ahx, p_aux=8)
+        for devices in ([0], [0, 0, 0]):
+            got, s = multi_select(devices, hllx, auxx, cardsx, cfgx.tau, MODE_CB_SMH, rx, bx, gather=0, criterion=crit, aux_hll=ahx, p_aux=8)
+            assert_same_pairs(got, want_c)
+            assert s["evaluated"] == st_c["evaluated"], (crit, devices, s, st_c)
+    with pytest.raises(pkg.SelhipError):
+        multi_select([0], hllx, auxx, cardsx, cfgx.tau, MODE_CB_SMH, rx, bx, gather=0, criterion=pkg.CRIT_HLL_A)     # no auxiliary sketches
     with pytest.raises(pkg.SelhipError):
         multi_select([0, 0], hll, aux, cards, cfg.tau, MODE_CB_SMH, r, b, gather=1)      # RCCL required, duplicate GPU
     with pytest.raises(pkg.SelhipError):
