@@ -360,3 +360,121 @@ int64_t orc_select(const uint8_t *hll, unsigned p, const uint64_t *aux_smh, unsi
     if (stats) { stats[0] = evaluated; stats[1] = survivors; }
     return total;
 }
+
+
+/* =================================================================================================
+ * Sort by cardinality: selection.cpp:251-256 calls std::sort(card_name.begin(), card_name.end(), by .second ascending).
+ * std::sort is NOT stable, so where cardinalities tie the order the reference prints depends on the algorithm of the
+ * C++ library it was built with.  That algorithm lives outside /root/reference: GNU libstdc++ (the g++ 11.4 of this image),
+ * <bits/stl_algo.h> std::__sort = introsort: median-of-three quicksort (std::__introsort_loop, threshold 16, depth limit
+ * 2*floor(log2 n), heap-sort fallback std::__partial_sort) followed by std::__final_insertion_sort.  Restated here on an
+ * index array (moving an index = moving the element): comp(a, b) = card[a] < card[b]; perm starts as the file-list order,
+ * as card_name does (selection.cpp:241-249).  Pinned by tests/golden/expected/ties_* (the reference binary's stdout on a
+ * set with duplicated sketches) and against the product's libstdc++ std::sort on random arrays with ties.
+ * ================================================================================================= */
+#define ORC_LESS(a, b) (card[(a)] < card[(b)])
+
+static void orc_ss_push_heap(int64_t *f, int64_t hole, int64_t top, int64_t value, const double *card)
+{
+    int64_t parent = (hole - 1) / 2;
+    while (hole > top && ORC_LESS(f[parent], value)) { f[hole] = f[parent]; hole = parent; parent = (hole - 1) / 2; }
+    f[hole] = value;
+}
+
+static void orc_ss_adjust_heap(int64_t *f, int64_t hole, int64_t len, int64_t value, const double *card)
+{
+    const int64_t top = hole;
+    int64_t child = hole;
+    while (child < (len - 1) / 2) {
+        child = 2 * (child + 1);
+        if (ORC_LESS(f[child], f[child - 1])) child--;
+        f[hole] = f[child];
+        hole = child;
+    }
+    if ((len & 1) == 0 && child == (len - 2) / 2) {
+        child = 2 * (child + 1);
+        f[hole] = f[child - 1];
+        hole = child - 1;
+    }
+    orc_ss_push_heap(f, hole, top, value, card);
+}
+
+static void orc_ss_heapsort(int64_t *f, int64_t n, const double *card)
+{   /* std::__partial_sort(first, last, last): __heap_select (= make_heap, the select loop is empty) + __sort_heap */
+    if (n >= 2) {
+        int64_t parent = (n - 2) / 2;
+        for (;;) { orc_ss_adjust_heap(f, parent, n, f[parent], card); if (parent == 0) break; parent--; }
+    }
+    int64_t last = n;
+    while (last > 1) { --last; const int64_t v = f[last]; f[last] = f[0]; orc_ss_adjust_heap(f, 0, last, v, card); }
+}
+
+static void orc_ss_unguarded_linear_insert(int64_t *last, const double *card)
+{
+    const int64_t val = *last;
+    int64_t *next = last - 1;
+    while (ORC_LESS(val, *next)) { *last = *next; last = next; --next; }
+    *last = val;
+}
+
+static void orc_ss_insertion_sort(int64_t *first, int64_t *last, const double *card)
+{
+    if (first == last) return;
+    for (int64_t *i = first + 1; i != last; ++i) {
+        if (ORC_LESS(*i, *first)) {
+            const int64_t val = *i;
+            memmove(first + 1, first, (size_t)(i - first) * sizeof(int64_t));
+            *first = val;
+        } else {
+            orc_ss_unguarded_linear_insert(i, card);
+        }
+    }
+}
+
+static void orc_ss_introsort_loop(int64_t *first, int64_t *last, int64_t depth, const double *card)
+{
+    while (last - first > 16) {
+        if (depth == 0) { orc_ss_heapsort(first, last - first, card); return; }
+        --depth;
+        /* __unguarded_partition_pivot: median of first+1, mid, last-1 moved to *first */
+        int64_t *mid = first + (last - first) / 2;
+        int64_t *a = first + 1, *b = mid, *c = last - 1, *r = first, t;
+#define ORC_SWAP(x, y) (t = *(x), *(x) = *(y), *(y) = t)
+        if (ORC_LESS(*a, *b)) {
+            if (ORC_LESS(*b, *c)) ORC_SWAP(r, b);
+            else if (ORC_LESS(*a, *c)) ORC_SWAP(r, c);
+            else ORC_SWAP(r, a);
+        } else if (ORC_LESS(*a, *c)) ORC_SWAP(r, a);
+        else if (ORC_LESS(*b, *c)) ORC_SWAP(r, c);
+        else ORC_SWAP(r, b);
+        /* __unguarded_partition(first + 1, last, pivot = first) */
+        int64_t *lo = first + 1, *hi = last;
+        for (;;) {
+            while (ORC_LESS(*lo, *first)) ++lo;
+            --hi;
+            while (ORC_LESS(*first, *hi)) --hi;
+            if (!(lo < hi)) break;
+            ORC_SWAP(lo, hi);
+            ++lo;
+        }
+#undef ORC_SWAP
+        orc_ss_introsort_loop(lo, last, depth, card);
+        last = lo;
+    }
+}
+
+void orc_std_sort_perm(const double *card, int64_t n, int64_t *perm)
+{
+    for (int64_t i = 0; i < n; ++i) perm[i] = i;
+    if (n <= 0) return;
+    int64_t lg = 0;
+    for (int64_t t = n; t > 1; t >>= 1) ++lg;                  /* std::__lg */
+    orc_ss_introsort_loop(perm, perm + n, 2 * lg, card);
+    if (n > 16) {                                              /* __final_insertion_sort */
+        orc_ss_insertion_sort(perm, perm + 16, card);
+        for (int64_t *i = perm + 16; i != perm + n; ++i) orc_ss_unguarded_linear_insert(i, card);
+    } else {
+        orc_ss_insertion_sort(perm, perm + n, card);
+    }
+}
+#undef ORC_LESS

@@ -88,6 +88,10 @@ int64_t orc_select(const uint8_t *hll, unsigned p, const uint64_t *aux_smh, unsi
 /* std::to_string(double) == sprintf("%f") (selection.cpp:288); returns strlen */
 int orc_format_jacc(double j, char *buf, size_t cap);
 
+/* selection.cpp:251-256: the permutation GNU libstdc++'s std::sort produces for `card` ascending, starting from the identity
+ * (file-list order) -- tie order included */
+void orc_std_sort_perm(const double *card, int64_t n, int64_t *perm);
+
 #ifdef __cplusplus
 }
 #endif

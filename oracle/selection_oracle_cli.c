@@ -7,9 +7,9 @@
  * experiments/src/time_smh.cpp:229-257), -S (print "evaluated survivors selected" to stderr) and
  * -F 0|1 (estimator flavour: 1 = FMA build of the reference (default), 0 = -ffp-contract=off build).
  *
- * Sort: the reference uses std::sort (unstable) on the double cardinality (selection.cpp:251-256).
- * The order among exactly equal cardinalities is therefore unspecified in the reference; this driver
- * uses a stable merge sort (ties keep file-list order).
+ * Sort: the reference uses std::sort (unstable) on the double cardinality (selection.cpp:251-256); the order among exactly
+ * equal cardinalities is whatever GNU libstdc++'s introsort leaves.  orc_std_sort_perm (selection_oracle.c) restates that
+ * algorithm, so ties land as in the reference binary (pinned by tests/golden/expected/ties_*).
  */
 #include "selection_oracle.h"
 
@@ -20,19 +20,6 @@
 #include <unistd.h>
 
 typedef struct { char *name; double card; int64_t idx; } entry_t;
-
-static void msort(entry_t *a, entry_t *tmp, int64_t n)
-{
-    if (n < 2) return;
-    int64_t h = n / 2;
-    msort(a, tmp, h);
-    msort(a + h, tmp, n - h);
-    int64_t i = 0, j = h, o = 0;
-    while (i < h && j < n) tmp[o++] = (a[j].card < a[i].card) ? a[j++] : a[i++];
-    while (i < h) tmp[o++] = a[i++];
-    while (j < n) tmp[o++] = a[j++];
-    memcpy(a, tmp, (size_t)n * sizeof(entry_t));
-}
 
 static char *trim(char *s)
 {   /* selection.cpp:56-57 */
@@ -128,9 +115,16 @@ int main(int argc, char **argv)
         }
     }
 
-    entry_t *tmp = (entry_t *)malloc((size_t)(N ? N : 1) * sizeof(entry_t));
-    msort(ent, tmp, N);
-    free(tmp);
+    {
+        entry_t *tmp = (entry_t *)malloc((size_t)(N ? N : 1) * sizeof(entry_t));
+        int64_t *perm = (int64_t *)malloc((size_t)(N ? N : 1) * sizeof(int64_t));
+        double *cv = (double *)malloc((size_t)(N ? N : 1) * sizeof(double));
+        for (int64_t i = 0; i < N; ++i) cv[i] = ent[i].card;
+        orc_std_sort_perm(cv, N, perm);
+        for (int64_t r = 0; r < N; ++r) tmp[r] = ent[perm[r]];
+        memcpy(ent, tmp, (size_t)N * sizeof(entry_t));
+        free(tmp); free(perm); free(cv);
+    }
     for (int64_t r = 0; r < N; ++r) {
         int64_t s = ent[r].idx;
         memcpy(hll_s + (size_t)r * hb, hll + (size_t)s * hb, hb);

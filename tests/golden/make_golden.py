@@ -54,6 +54,38 @@ def write_synth_files(cfg, directory: Path):
     return lst
 
 
+# ---- tie set: duplicated sketches => exactly equal cardinalities under distinct names.  selection.cpp:251-256 sorts with the
+# UNSTABLE std::sort, so which of two equal genomes ranks first (hence prints first) is decided by libstdc++'s introsort;
+# 60 entries (> the 16-element insertion-sort threshold) make the quicksort phase matter.
+TIES_BASE = SynthConfig("ties base", 12, 128, 0.9, 0x5EED0071, p_aux=8, n_sh_lo=20000, n_sh_hi=20000)
+TIES_COPIES = 5
+TIES_CASES = [("smh_a", 1024, "0.9"), ("smh_a", 1024, "0.5"), ("hll_a", 256, "0.9"), ("hll_an", 256, "0.9")]
+
+
+def ties_order():
+    """list position -> base genome (seeded shuffle of TIES_COPIES copies of every base genome)"""
+    order = np.repeat(np.arange(TIES_BASE.n_genomes), TIES_COPIES)
+    np.random.default_rng(0x71E5).shuffle(order)
+    return order
+
+
+def write_tie_files(directory: Path):
+    """t<idx>.hll / .smh128 / .hll_8 (copies of the base genomes' sketches, in the reference's formats); returns the list file"""
+    host = pkg.host_lib()
+    cfg = TIES_BASE
+    hll, aux, aux_hll = pkg.synth_host(cfg)
+    names = []
+    for idx, g in enumerate(ties_order()):
+        base = directory / f"t{idx:03d}"
+        assert host.selhost_write_hll(str(base).encode() + b".hll", hll[g].ctypes.data, 14) == 0
+        assert host.selhost_write_smh(str(base).encode() + f".smh{cfg.m}".encode(), aux[g].ctypes.data, cfg.m) == 0
+        assert host.selhost_write_hll(str(base).encode() + f".hll_{cfg.p_aux}".encode(), aux_hll[g].ctypes.data, cfg.p_aux) == 0
+        names.append(f"t{idx:03d}")
+    lst = directory / "list.txt"
+    lst.write_text("\n".join(names) + "\n")
+    return lst
+
+
 def run(binary, args, cwd):
     return subprocess.run([str(REF / binary)] + args, cwd=cwd, check=True, capture_output=True, text=True).stdout
 
@@ -93,6 +125,15 @@ def main():
                 (exp / f"{name}_kat_hll.{flavour}.txt").write_text(run(binary, [".hll"] + first, td))
                 (exp / f"{name}_kat_hll_8.{flavour}.txt").write_text(run(binary, [".hll_8"] + first, td))
         print("golden:", name)
+    # ---- tie order of the reference's std::sort ------------------------------------------------------------
+    with tempfile.TemporaryDirectory() as td:
+        td = Path(td)
+        write_tie_files(td)
+        for flavour, binary in (("fma", "selection"), ("nofma", "selection_nofma")):
+            for crit, a, h in TIES_CASES:
+                out = run(binary, ["-l", "list.txt", "-t", "4", "-c", crit, "-a", str(a), "-h", h], td)
+                (exp / f"ties_{crit}_a{a}_h{h}.{flavour}.txt").write_text(out)
+    print("golden: ties")
     print("done ->", exp)
 
 

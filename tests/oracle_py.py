@@ -29,6 +29,8 @@ class Oracle:
         L.orc_select.argtypes = [C.c_void_p, C.c_uint, C.c_void_p, C.c_uint, C.c_void_p, C.c_uint, C.c_void_p, C.c_int64,
                                  C.c_float, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_int]
         L.orc_set_fma.argtypes = [C.c_int]
+        L.orc_std_sort_perm.argtypes = [C.c_void_p, C.c_int64, C.c_void_p]
+        L.orc_std_sort_perm.restype = None
         L.orc_cb.argtypes = [C.c_double, C.c_double, C.c_double]
 
     def set_fma(self, on):
@@ -61,6 +63,13 @@ class Oracle:
         v1 = np.ascontiguousarray(v1, dtype=np.uint64)
         v2 = np.ascontiguousarray(v2, dtype=np.uint64)
         return bool(self.lib.orc_smh_a(v1.ctypes.data, v2.ctypes.data, v1.size, n_rows, n_bands))
+
+    def std_sort_perm(self, cards):
+        """permutation of selection.cpp:251-256's std::sort (GNU libstdc++ introsort restated), ties included"""
+        cards = np.ascontiguousarray(cards, dtype=np.float64)
+        perm = np.empty(len(cards), dtype=np.int64)
+        self.lib.orc_std_sort_perm(cards.ctypes.data, len(cards), perm.ctypes.data)
+        return perm
 
     def banding(self, m, tau, cuda_variant=False):
         r, b = C.c_int(), C.c_int()

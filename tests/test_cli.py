@@ -78,3 +78,29 @@ def test_selection_cli_out_of_core_and_result_file(tmp_path):
     assert out.returncode == 0 and out.stdout == "", out.stderr
     out = subprocess.run([str(BIN / "selection"), "-r", str(f)], capture_output=True, text=True)
     assert out.returncode == 0 and out.stdout == want
+
+
+@pytest.mark.gpu
+def test_selection_cli_tie_order_matches_the_reference_binary(tmp_path):
+    """duplicated sketches (equal cardinalities, distinct names): `bin/selection` and the Python driver print the reference binary's
+    lines, tie order included (tests/golden/expected/ties_*, made by oracle/_ref/selection; see test_oracle_golden.py)"""
+    import sys
+    sys.path.insert(0, str(GOLDEN))
+    import make_golden
+    import cuda_selection_criteria_amd as pkg
+    make_golden.write_tie_files(tmp_path)
+    for crit, a, h in make_golden.TIES_CASES:
+        for flag, flavour in (("1", "fma"), ("0", "nofma")):
+            want = (EXP / f"ties_{crit}_a{a}_h{h}.{flavour}.txt").read_text()
+            out = subprocess.run([str(BIN / "selection"), "-l", "list.txt", "-h", h, "-a", str(a), "-c", crit, "-F", flag],
+                                 cwd=tmp_path, capture_output=True, text=True)
+            assert out.returncode == 0, out.stderr
+            assert out.stdout == want, (crit, a, h, flavour)
+    import os
+    cwd = os.getcwd()
+    os.chdir(tmp_path)
+    try:
+        got = pkg.select_from_filelist("list.txt", 0.9, 1024)
+        assert got == (EXP / "ties_smh_a_a1024_h0.9.fma.txt").read_text()
+    finally:
+        os.chdir(cwd)

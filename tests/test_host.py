@@ -256,3 +256,22 @@ def test_shard_rows_equal_pairs():
     pc = D.pair_counts(3000, b, hi)
     assert pc.sum() == int(np.maximum(hi.astype(np.int64) - np.arange(3000), 0).sum())
     assert pc.max() <= pc.mean() * 1.05 + 3000
+
+
+def test_sort_by_card_is_the_reference_std_sort_ties_included(oracle):
+    """selhost_sort_by_card (libstdc++ std::sort on (index, card) pairs, same comparator as selection.cpp:251-256) against the
+    oracle's restatement of the introsort algorithm: random arrays with many equal cardinalities, sorted / reversed / organ-pipe
+    inputs, sizes around the 16-element insertion-sort threshold"""
+    rng = np.random.default_rng(5)
+    for t in range(300):
+        n = int(rng.integers(0, 3000)) if t % 7 else int(rng.integers(0, 40))
+        vals = rng.integers(0, max(2, n // int(rng.integers(1, 20))), n).astype(np.float64) * 1.5
+        if t % 11 == 0:
+            vals = np.sort(vals)
+        if t % 13 == 0:
+            vals = np.sort(vals)[::-1].copy()
+        assert np.array_equal(oracle.std_sort_perm(vals), pkg.sort_by_card(vals)), t
+    for n in (15, 16, 17, 33, 100, 5000, 100_000):
+        v = np.concatenate([np.arange(n // 2), np.arange(n - n // 2)[::-1]]).astype(np.float64)
+        assert np.array_equal(oracle.std_sort_perm(v), pkg.sort_by_card(v))
+        assert np.array_equal(oracle.std_sort_perm(np.zeros(n)), pkg.sort_by_card(np.zeros(n)))

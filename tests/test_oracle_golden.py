@@ -128,3 +128,25 @@ def test_synthetic_sets(tmp_path, oracle, name):
                     assert v == float.fromhex(t[-1]), (name, line)
         finally:
             oracle.set_fma(1)
+
+
+@pytest.mark.parametrize("flavour,fma", [("fma", 1), ("nofma", 0)])
+def test_tie_order_matches_the_reference_binary(tmp_path, flavour, fma):
+    """selection.cpp:251-256 sorts by cardinality with the unstable std::sort; with duplicated sketches (equal cardinalities under
+    distinct names, 60 list entries) the printed order shows which of two equal genomes ranks first.  The oracle restates GNU
+    libstdc++'s introsort (orc_std_sort_perm) and must print what the reference binary printed (tests/golden/expected/ties_*)."""
+    import sys
+    sys.path.insert(0, str(GOLDEN))
+    import make_golden
+    make_golden.write_tie_files(tmp_path)
+    for crit, a, h in make_golden.TIES_CASES:
+        got = cli(["-l", "list.txt", "-c", crit, "-a", str(a), "-h", h, "-F", str(fma)], cwd=tmp_path)
+        assert got == (EXP / f"ties_{crit}_a{a}_h{h}.{flavour}.txt").read_text(), (crit, a, h)
+
+
+def test_tie_set_really_has_ties(oracle):
+    import sys
+    sys.path.insert(0, str(GOLDEN))
+    import make_golden
+    order = make_golden.ties_order()
+    assert len(order) == 60 and len(set(order.tolist())) == 12
