@@ -36,7 +36,7 @@ __device__ __forceinline__ uint32_t dpp_row_shr(uint32_t x) {
 // all-pairs joins) bucket index -> (genome, band, position) is shifts and masks instead of 64-bit divisions.
 __device__ __forceinline__ void sig_build_body(long long block, const u64* __restrict__ aux, int n, int m, int r, int nb, int n_pad,
                                                uint32_t* __restrict__ sigQ, uint32_t* __restrict__ sigT, uint32_t* __restrict__ sigP,
-                                               uint32_t* __restrict__ sigG) {
+                                               uint32_t* __restrict__ sigG, int pk_shift) {
     uint16_t* const sigP16 = reinterpret_cast<uint16_t*>(sigP);
     uint16_t* const sigG16 = reinterpret_cast<uint16_t*>(sigG);          // genome-major twin of sigP: [g][(nb + 1) / 2] dwords
     const long long g_pitch = 2ll * ((nb + 1) / 2);
@@ -68,8 +68,8 @@ __device__ __forceinline__ void sig_build_body(long long block, const u64* __res
             const uint32_t sig = hl ^ hh;
             sigQ[(long long)g * nb + b] = sig;
             sigT[(long long)b * n_pad + g] = sig;
-            sigP16[((long long)(b >> 1) * n_pad + g) * 2 + (b & 1)] = (uint16_t)(sig >> 16);
-            sigG16[(long long)g * g_pitch + b] = (uint16_t)(sig >> 16);
+            sigP16[((long long)(b >> 1) * n_pad + g) * 2 + (b & 1)] = (uint16_t)(sig >> pk_shift);
+            sigG16[(long long)g * g_pitch + b] = (uint16_t)(sig >> pk_shift);
         }
     } else {
         const long long t = block * kBlock + threadIdx.x;                      // (genome, band)
@@ -85,8 +85,8 @@ __device__ __forceinline__ void sig_build_body(long long block, const u64* __res
         const uint32_t sig = hl ^ hh;
         sigQ[(long long)g * nb + b] = sig;
         sigT[(long long)b * n_pad + g] = sig;
-        sigP16[((long long)(b >> 1) * n_pad + g) * 2 + (b & 1)] = (uint16_t)(sig >> 16);
-        sigG16[(long long)g * g_pitch + b] = (uint16_t)(sig >> 16);
+        sigP16[((long long)(b >> 1) * n_pad + g) * 2 + (b & 1)] = (uint16_t)(sig >> pk_shift);
+        sigG16[(long long)g * g_pitch + b] = (uint16_t)(sig >> pk_shift);
     }
 }
 
@@ -97,14 +97,14 @@ void sig_build_kernel(const u64* __restrict__ aux, int n, int m, int r, int nb, 
                       uint32_t* __restrict__ sigQ, uint32_t* __restrict__ sigT, uint32_t* __restrict__ sigP, uint32_t* __restrict__ sigG,
                       int bounds_blocks, const double* __restrict__ cards, double tau, int use_cb, RowMap rm,
                       u64* __restrict__ ecard, int* __restrict__ hi, PassCounters* __restrict__ pc, int* __restrict__ csr_zero, int cand_begin,
-                      u64* __restrict__ seg_zero, int seg_zero_n) {
+                      u64* __restrict__ seg_zero, int seg_zero_n, int pk_shift) {
     if ((int)blockIdx.x < bounds_blocks) {
         const int t = (int)(blockIdx.x * kBlock + threadIdx.x);
         for (int j = t; j < seg_zero_n; j += bounds_blocks * kBlock) seg_zero[j] = 0;      // the join's append-segment counters of this pass
         cb_bounds_body(t, cards, n, tau, use_cb, rm, ecard, hi, pc, csr_zero, cand_begin);
         return;
     }
-    sig_build_body((long long)blockIdx.x - bounds_blocks, aux, n, m, r, nb, n_pad, sigQ, sigT, sigP, sigG);
+    sig_build_body((long long)blockIdx.x - bounds_blocks, aux, n, m, r, nb, n_pad, sigQ, sigT, sigP, sigG, pk_shift);
 }
 
 // sig_join_kernel<NB>: all-pairs "some band signature equal", entirely on the vector unit.
@@ -328,6 +328,55 @@ __device__ __forceinline__ void joinl_accum(us2_t (&acc)[T][4], const uint32_t (
     }
 }
 
+// 15-bit form ("join_bits" = 15): every instruction of the loop is a VGPR-only VOP2, the class that two waves co-issue
+// (2.07 instead of 4.07 cycles, profiles/r02_valu_rate.txt) -- and they only co-issue with EACH OTHER, which is why the packed
+// min above never sees the benefit of its plain xor (same file, rows "mix: v_xor_b32 / v_pk_min_u16": 3.75-3.93 cycles per
+// instruction).  The packed dword holds two 15-bit signatures with a clear top bit per half, so
+//     t = c ^ q                    both halves in [0, 0x7FFF]
+//     u = t + 0x7FFF7FFF           no carry between the halves; bit 15 / bit 31 = "half != 0"
+//     acc &= u                     a cleared flag bit = some band's 15-bit signature was equal
+// Inline asm keeps the compiler from fusing xor+add into v_xad_u32 or and+or forms (VOP3: full cost, and unpairable).
+template <int ND, int T, int OFF, int CNT>
+__device__ __forceinline__ void joinl_accum15(uint32_t (&acc)[T][4], const uint32_t (&c)[T][ND], const uint32_t (&q)[CNT], uint32_t k7) {
+#pragma unroll
+    for (int d = 0; d < CNT; d += 4) {
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+            uint32_t x[4];
+#pragma unroll
+            for (int a = 0; a < 4; ++a) asm("v_xor_b32 %0, %1, %2" : "=v"(x[a]) : "v"(c[t][OFF + d + a]), "v"(q[d + a]));
+#pragma unroll
+            for (int a = 0; a < 4; ++a) asm("v_add_u32 %0, %1, %2" : "=v"(x[a]) : "v"(x[a]), "v"(k7));
+#pragma unroll
+            for (int a = 0; a < 4; ++a) asm("v_and_b32 %0, %1, %2" : "=v"(acc[t][a]) : "v"(acc[t][a]), "v"(x[a]));
+        }
+    }
+}
+
+template <int T>
+__device__ __forceinline__ void joinl_reset15(uint32_t (&acc)[T][4]) {
+#pragma unroll
+    for (int t = 0; t < T; ++t)
+#pragma unroll
+        for (int a = 0; a < 4; ++a) acc[t][a] = 0xFFFFFFFFu;
+}
+
+template <int T>
+__device__ __forceinline__ void joinl_test15(const uint32_t (&acc)[T][4], int i, int k0, int lane, int z0, int n,
+                                             const int* __restrict__ hi, WaveAppender& app) {
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+        const uint32_t f = (acc[t][0] & acc[t][1]) & (acc[t][2] & acc[t][3]) & 0x80008000u;
+        const u64 mm = __ballot(f != 0x80008000u);
+        if (mm) {
+            const int lo = max(i + 1, z0);
+            const int hk = min(hi[i], n - 1);
+            const int k = k0 + t * kWave;
+            app.push(((mm >> lane) & 1ull) && k >= lo && k <= hk, i, k, lane);
+        }
+    }
+}
+
 template <int T>
 __device__ __forceinline__ void joinl_reset(us2_t (&acc)[T][4]) {
 #pragma unroll
@@ -368,7 +417,7 @@ __device__ __forceinline__ void joinl_load(uint32_t (&q)[CH], const uint32_t* ro
 
 constexpr int kJoinTilePadRows = 2;        // look-ahead reads past the last staged row stay inside the allocation
 
-template <int ND, int T, int WPB>
+template <int ND, int T, int WPB, bool SIG15>
 __global__ __launch_bounds__(WPB * kWave)
 void sigl_join_kernel(const uint32_t* __restrict__ sigP, const uint32_t* __restrict__ sigG, int n, int n_pad,
                       const int* __restrict__ hi, const PassCounters* __restrict__ pc_in,
@@ -424,41 +473,50 @@ void sigl_join_kernel(const uint32_t* __restrict__ sigP, const uint32_t* __restr
     constexpr int CH = ND < 16 ? ND : 16;                                      // dwords per chunk (one register set)
     constexpr int NCH = ND / CH;                                               // chunks per row: 1 (<= 32 bands), 2 (64), 4 (128)
     const int rows = i_hi - i_lo;
-    us2_t acc[T][4];
+    using acc_t = typename std::conditional<SIG15, uint32_t, us2_t>::type;
+    acc_t acc[T][4];
+    uint32_t k7 = 0x7FFF7FFFu;
+    asm volatile("" : "+v"(k7));                                               // keep the constant in a VGPR (a literal operand is not a plain VOP2)
+#define SELHIP_JL_RESET()            do { if constexpr (SIG15) joinl_reset15<T>(acc); else joinl_reset<T>(acc); } while (0)
+#define SELHIP_JL_ACCUM(OFF, Q)      do { if constexpr (SIG15) joinl_accum15<ND, T, OFF, CH>(acc, c, Q, k7); else joinl_accum<ND, T, OFF, CH>(acc, c, Q); } while (0)
+#define SELHIP_JL_TEST(I)            do { if constexpr (SIG15) joinl_test15<T>(acc, I, k0, lane, z0, n, hi, app); else joinl_test<T>(acc, I, k0, lane, z0, n, hi, app); } while (0)
     uint32_t qa[CH], qb[CH];
     joinl_load<CH>(qa, tile_lds);
     if constexpr (NCH == 1) {
         for (int r = 0; r < rows; r += 2) {
             joinl_load<CH>(qb, tile_lds + (r + 1) * ND);
-            joinl_reset<T>(acc);
-            joinl_accum<ND, T, 0, CH>(acc, c, qa);
-            joinl_test<T>(acc, i_lo + r, k0, lane, z0, n, hi, app);
+            SELHIP_JL_RESET();
+            SELHIP_JL_ACCUM(0, qa);
+            SELHIP_JL_TEST(i_lo + r);
             if (r + 1 >= rows) break;
             joinl_load<CH>(qa, tile_lds + (r + 2) * ND);
-            joinl_reset<T>(acc);
-            joinl_accum<ND, T, 0, CH>(acc, c, qb);
-            joinl_test<T>(acc, i_lo + r + 1, k0, lane, z0, n, hi, app);
+            SELHIP_JL_RESET();
+            SELHIP_JL_ACCUM(0, qb);
+            SELHIP_JL_TEST(i_lo + r + 1);
         }
     } else {
         for (int r = 0; r < rows; ++r) {
             const uint32_t* row = tile_lds + r * ND;
-            joinl_reset<T>(acc);
+            SELHIP_JL_RESET();
             joinl_load<CH>(qb, row + CH);
-            joinl_accum<ND, T, 0, CH>(acc, c, qa);
+            SELHIP_JL_ACCUM(0, qa);
             if constexpr (NCH == 2) {
                 joinl_load<CH>(qa, row + ND);                                  // chunk 0 of the next row
-                joinl_accum<ND, T, CH, CH>(acc, c, qb);
+                SELHIP_JL_ACCUM(CH, qb);
             } else {
                 joinl_load<CH>(qa, row + 2 * CH);
-                joinl_accum<ND, T, CH, CH>(acc, c, qb);
+                SELHIP_JL_ACCUM(CH, qb);
                 joinl_load<CH>(qb, row + 3 * CH);
-                joinl_accum<ND, T, 2 * CH, CH>(acc, c, qa);
+                SELHIP_JL_ACCUM(2 * CH, qa);
                 joinl_load<CH>(qa, row + ND);
-                joinl_accum<ND, T, 3 * CH, CH>(acc, c, qb);
+                SELHIP_JL_ACCUM(3 * CH, qb);
             }
-            joinl_test<T>(acc, i_lo + r, k0, lane, z0, n, hi, app);
+            SELHIP_JL_TEST(i_lo + r);
         }
     }
+#undef SELHIP_JL_RESET
+#undef SELHIP_JL_ACCUM
+#undef SELHIP_JL_TEST
     app.flush(lane);
 }
 

@@ -22,6 +22,7 @@
 #include <rocprim/device/device_radix_sort.hpp>   // ALGO_HASHJOIN only: the key sort is a library call, everything else is hand-written
 
 #include <algorithm>
+#include <type_traits>
 #include <array>
 #include <chrono>
 #include <cmath>
@@ -151,7 +152,7 @@ struct selhip_ctx {
     int verify_fb = 0;                  // test hook: force the collision fallback of verify16_kernel
     int join_wpb = 4;                   // 16-bit join: waves per block (DPP form: 1 or 4; LDS form: 4 or 8 -- the waves of a block share the staged query tile)
     int join_db = 1;                    // 16-bit join: double-buffered query batches
-    int join_bits = 16;                 // signature width of the all-pairs join: 16 (packed, + 32-bit filter) or 32
+    int join_bits = 16;                 // signature width of the all-pairs join: 16 (packed min), 15 (LDS form only: flag arithmetic, all plain VOP2) or 32
     int join_q = 1;                     // 16-bit join, query side: 1 = tile staged in LDS, broadcast reads (sigl_join_kernel), 0 = DPP row broadcast (sig16_join_kernel)
     long long enum_pairs = kEnumPairs;  // hll_a / hll_an as first criterion: pairs listed per sub-pass (test hook "enum_pairs")
     int init_cap = 0;                   // test hook: initial capacity of the survivor / candidate lists (0 = sized from the workload)
@@ -377,9 +378,14 @@ hipError_t launch_joinl_w(selhip_ctx* c, const StageIO& io, int n_pad, int rb, i
     if (blocks > 0x7FFFFFFFll) return hipErrorInvalidValue;
     const size_t smem = (size_t)WPB * kAppendCap * sizeof(selhip_int2_t) + (size_t)(qt + kJoinTilePadRows) * ND * 4;
     if (smem > 64 * 1024) return hipErrorInvalidValue;                                   // join_qt is capped so that this cannot happen
-    hipLaunchKernelGGL((sigl_join_kernel<ND, T, WPB>), dim3((unsigned)blocks), dim3(WPB * kWave), smem, io.st,
-                       c->sigP.p, c->sigG.p, n, n_pad, c->hi.p, c->pc.p, rm, n_tiles, group_base, qt,
-                       io.cand, io.cap, io.seg_cnt);
+    if (c->join_bits == 15)
+        hipLaunchKernelGGL((sigl_join_kernel<ND, T, WPB, true>), dim3((unsigned)blocks), dim3(WPB * kWave), smem, io.st,
+                           c->sigP.p, c->sigG.p, n, n_pad, c->hi.p, c->pc.p, rm, n_tiles, group_base, qt,
+                           io.cand, io.cap, io.seg_cnt);
+    else
+        hipLaunchKernelGGL((sigl_join_kernel<ND, T, WPB, false>), dim3((unsigned)blocks), dim3(WPB * kWave), smem, io.st,
+                           c->sigP.p, c->sigG.p, n, n_pad, c->hi.p, c->pc.p, rm, n_tiles, group_base, qt,
+                           io.cand, io.cap, io.seg_cnt);
     return hipGetLastError();
 }
 
@@ -407,7 +413,7 @@ hipError_t launch_sig_build(selhip_ctx* c, int n_rows, int n_bands, bool with_bo
                        c->d_aux, n, c->m, n_rows, n_bands, n_pad, c->sigQ.p, c->sigT.p, c->sigP.p, c->sigG.p,
                        bounds_blocks, c->d_cards, tau, c->mode == SELHIP_MODE_CB_SMH ? 1 : 0, row_map(c, rb, re), c->ecard.p, c->hi.p, c->pc.p,
                        (c->p == 14 && c->group_stage2) ? c->csr_cnt.p : nullptr, (int)c->cand_begin,
-                       with_bounds ? c->seg_cnt.p : nullptr, with_bounds ? (int)c->seg_cnt.cap : 0);
+                       with_bounds ? c->seg_cnt.p : nullptr, with_bounds ? (int)c->seg_cnt.cap : 0, c->join_bits == 15 ? 17 : 16);
     return hipGetLastError();
 }
 
@@ -416,7 +422,7 @@ hipError_t launch_stage1_sig(selhip_ctx* c, const StageIO& io, int n_rows, int n
     const int n = (int)c->n;
     const int n_pad = ((n + kWave - 1) / kWave) * kWave;
     hipError_t e = hipSuccess;
-    if (c->join_bits == 16) {
+    if (c->join_bits == 16 || c->join_bits == 15) {
         {
             TimerScope t(c, T_JOIN, io.st);
             switch (n_bands) {
@@ -678,7 +684,7 @@ int enqueue_pass(selhip_ctx* c) {
     io.seg_cnt = c->seg_cnt.p + (size_t)kAppendSegs * kSegStride;
     // the survivors of the 16-bit signature path are the final list when smh_a is the only criterion: verify16_kernel
     // then tallies them per query row itself (no csr_count launch)
-    const bool count_in_verify = crit == SELHIP_CRIT_SMH_A && use_sig && !use_hash && c->join_bits == 16 && c->p == 14 && c->group_stage2;
+    const bool count_in_verify = crit == SELHIP_CRIT_SMH_A && use_sig && !use_hash && c->join_bits <= 16 && c->p == 14 && c->group_stage2;
     if (count_in_verify) io.row_cnt = c->csr_cnt.p;
     const selhip_int2_t* final_list = c->surv.p;
     const u64* final_count = &io.pc->n_survivors;
@@ -960,7 +966,7 @@ int selhip_ctx_set_param(selhip_ctx* c, const char* name, int value) {
         return SELHIP_OK;
     }
     if (!std::strcmp(name, "join_bits")) {
-        if (value != 16 && value != 32) { set_err(&c->err, "join_bits must be 16 or 32"); return SELHIP_E_BADARG; }
+        if (value != 15 && value != 16 && value != 32) { set_err(&c->err, "join_bits must be 15, 16 or 32"); return SELHIP_E_BADARG; }
         c->join_bits = value;
         return SELHIP_OK;
     }
@@ -1128,10 +1134,10 @@ int selhip_ctx_run_async(selhip_ctx* c, int mode, int algo, float tau_f, int n_r
     std::memset(&c->last, 0, sizeof c->last);
     if (c->n == 0 || row_begin == row_end) { c->pending = false; c->have_run = true; return SELHIP_OK; }
     size_t surv_cap = std::max<size_t>(c->surv.cap, std::max<size_t>((size_t)1 << 20, (size_t)c->n * 16));
-    if (needs_smh && c->join_bits == 16 && algo != SELHIP_ALGO_STREAM && algo != SELHIP_ALGO_HASHJOIN && sig_supported(c->m, n_rows, n_bands)) {
+    if (needs_smh && c->join_bits <= 16 && algo != SELHIP_ALGO_STREAM && algo != SELHIP_ALGO_HASHJOIN && sig_supported(c->m, n_rows, n_bands)) {
         // the 16-bit join passes ~n_bands * 2^-16 of the pairs it compares on to the 32-bit filter: size the lists for that
         // up front (an overflow would only cost one repeated pass)
-        const double expect = (double)pair_bound(c->n, (int)row_begin, (int)row_end) / std::max(1, c->il_parts) * n_bands / 65536.0;
+        const double expect = (double)pair_bound(c->n, (int)row_begin, (int)row_end) / std::max(1, c->il_parts) * n_bands / (c->join_bits == 15 ? 32768.0 : 65536.0);
         surv_cap = std::max(surv_cap, (size_t)std::min(expect * 1.25 + 65536.0, (double)((size_t)1 << 26)));
     }
     if (c->init_cap > 0) surv_cap = std::max<size_t>(c->surv.cap, (size_t)c->init_cap);       // test hook: start small, grow on overflow

@@ -7,8 +7,8 @@ ROOT = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT))
 import cuda_selection_criteria_amd as pkg
 
-VARIANTS = [  # (join_q: 1 = LDS query tile / 0 = DPP broadcast, join_wpb, join_qt)
-    (0, 1, 128), (0, 4, 128), (1, 4, 64), (1, 8, 64), (1, 4, 96), (1, 4, 128), (1, 8, 128), (1, 4, 256), (1, 8, 256),
+VARIANTS = [  # (join_bits, join_q: 1 = LDS query tile / 0 = DPP broadcast, join_wpb, join_qt)
+    (16, 0, 1, 128), (16, 1, 4, 64), (16, 1, 4, 128), (15, 1, 4, 64), (15, 1, 8, 64), (15, 1, 4, 96), (15, 1, 4, 128), (15, 1, 8, 128), (15, 1, 4, 256),
 ]
 for wl in sys.argv[1:] or ("cfg3", "cfg4"):
     cfg = pkg.SYNTH_CONFIGS[wl]
@@ -16,14 +16,15 @@ for wl in sys.argv[1:] or ("cfg3", "cfg4"):
     r, b = pkg.banding(cfg.m, cfg.tau)
     sel = pkg.Selector(0); sel.attach(hll, aux, cards)
     ref = None
-    for q, wpb, qt in VARIANTS:
-        sel.set_param("join_q", q); sel.set_param("join_wpb", wpb); sel.set_param("join_qt", qt)
+    for bits, q, wpb, qt in VARIANTS:
+        sel.set_param("join_bits", bits); sel.set_param("join_q", q); sel.set_param("join_wpb", wpb); sel.set_param("join_qt", qt)
         for _ in range(2): sel.run(cfg.tau, pkg.MODE_SMH, r, b, algo=pkg.ALGO_SIG, fetch=False)
         st = sel.stats()
+        st = {k: v for k, v in st.items() if k != "candidates"} if False else st
         if ref is None: ref = st
         sel.timing(True)
         for _ in range(6): sel.run(cfg.tau, pkg.MODE_SMH, r, b, algo=pkg.ALGO_SIG, fetch=False)
-        print(wl, "q=%d wpb=%d qt=%d" % (q, wpb, qt), "sigbuild=%.1f join=%.1f verify=%.1f total=%.1f us" % tuple(sel.kernel_ms(k) * 1e3 for k in ("sigbuild", "join", "verify", "total")),
+        print(wl, "bits=%d q=%d wpb=%d qt=%d" % (bits, q, wpb, qt), "sigbuild=%.1f join=%.1f verify=%.1f total=%.1f us" % tuple(sel.kernel_ms(k) * 1e3 for k in ("sigbuild", "join", "verify", "total")),
               "OK" if st == ref else "MISMATCH %s vs %s" % (st, ref), flush=True)
         sel.timing(False)
     sel.close()

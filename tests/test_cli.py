@@ -104,3 +104,24 @@ def test_selection_cli_tie_order_matches_the_reference_binary(tmp_path):
         assert got == (EXP / "ties_smh_a_a1024_h0.9.fma.txt").read_text()
     finally:
         os.chdir(cwd)
+
+
+@pytest.mark.gpu
+def test_comparison_and_timing_experiments(tmp_path):
+    """scripts/experiments.py: the reference's CPU-vs-GPU comparison method (run_comparison_experiment.sh:57-112: tau = 0.01, keyed
+    join of the two outputs, |sim_cpu - sim_gpu| with eps 1e-6) as a runnable artefact -- every pair on both sides, diff 0 -- and
+    its timing CSV (run_time_experiment.sh)"""
+    import csv
+    import sys
+    out = tmp_path / "cmp.csv"
+    r = subprocess.run([sys.executable, str(ROOT / "scripts" / "experiments.py"), "compare", "-l", "influenza_filelist.txt", "-a", "512", "4096",
+                        "-h", "0.01", "-o", str(out)], cwd=GOLDEN, capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    rows = list(csv.DictReader(open(out)))
+    assert len(rows) == 27 + 41 and all(x["diff"] == "0" for x in rows)          # SURVEY.md 8c: 27 pairs at m=64, 41 at m=512
+    out2 = tmp_path / "time.csv"
+    r = subprocess.run([sys.executable, str(ROOT / "scripts" / "experiments.py"), "time", "-l", "influenza_filelist.txt", "-m", "256", "-h", "0.9",
+                        "-t", "2", "-o", str(out2)], cwd=GOLDEN, capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    rows = list(csv.DictReader(open(out2)))
+    assert {(x["impl"], x["criterio"]) for x in rows} >= {("gpu", "smh_a"), ("gpu", "CB+smh_a"), ("cpu", "smh_a"), ("cpu", "CB+smh_a")}

@@ -262,7 +262,8 @@ def test_join_and_histogram_variants(oracle):
             #  tile height)
             for bits, db, fb, q, wpb, qt in ((16, 1, 0, 1, 4, 64), (16, 1, 0, 1, 8, 128), (16, 1, 0, 1, 4, 16), (16, 1, 0, 1, 8, 256),
                                              (16, 1, 0, 0, 1, 128), (16, 0, 0, 0, 4, 96), (32, 0, 0, 0, 1, 128),
-                                             (16, 1, 1, 1, 4, 64), (16, 0, 1, 0, 4, 128)):
+                                             (16, 1, 1, 1, 4, 64), (16, 0, 1, 0, 4, 128),
+                                             (15, 1, 0, 1, 4, 64), (15, 1, 0, 1, 8, 128), (15, 1, 0, 0, 1, 128), (15, 1, 1, 1, 4, 32)):
                 sel.set_param("join_bits", bits); sel.set_param("join_db", db); sel.set_param("verify_fb", fb)
                 sel.set_param("join_q", q); sel.set_param("join_wpb", wpb); sel.set_param("join_qt", qt)
                 assert_same_pairs(sel.run(tau, MODE_CB_SMH, r, b, algo=ALGO_SIG), want)
