@@ -75,6 +75,7 @@ def parse():
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
                     help="gloo = rehearsal of the multi-rank logic on a box with fewer GPUs than ranks (records staged through the host)")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="target CPU time of each baseline sample")
+    ap.add_argument("--param", action="append", default=[], metavar="NAME=VALUE", help="selhip_ctx_set_param (development A/B runs), repeatable")
     return ap.parse_args()
 
 
@@ -160,6 +161,9 @@ def main():
     if args.join_q >= 0:
         join_q = int(args.join_q != 0)
         sel.set_param("join_q", join_q)
+    for kv in args.param:
+        name, _, val = kv.partition("=")
+        sel.set_param(name, int(val))
     if world > 1:
         # shard the pair space by interleaved blocks of query rows: rank r owns the blocks b with b % world == r, i.e. an
         # equal share of the pairs AND of the survivors (stage 2) -- a contiguous equal-pair cut would leave the last rank

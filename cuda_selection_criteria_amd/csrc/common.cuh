@@ -28,6 +28,7 @@ struct PassCounters {
     int z0p1;            // 1 + first rank with e != 0; 0 (the memset value) = none, i.e. z0 = n
     int unsorted;        // set if cards are not ascending
 };
+static_assert(sizeof(PassCounters) % 8 == 0, "counter blocks are cleared and copied as u64 words");
 
 
 // ---------------------------------------------------------------------------------------------
@@ -73,6 +74,7 @@ constexpr int kAppendCap = 2 * kWave;          // count < 64 before a push, a pu
 // uses segment blockIdx % kAppendSegs).  Measured (gpurun_out/r02/join_dbg.txt, PMC in DESIGN.md section 4): with ONE counter
 // the join of cfg4 was bound by the ~87 returning atomics per microsecond a single address sustains -- every wave flushes
 // at least once, 153 000 waves = 1.8 ms of a 2.1 ms kernel, and halving the tile height doubled the kernel time.
+constexpr int kCounterBlocks = 9;               // counter blocks per pass: block 0 + one per pipeline chunk (kMaxChunks = 8)
 constexpr int kAppendSegs = 64;
 constexpr int kSegStride = 16;                 // u64 slots between two segment counters (128 B: one cache line each)
 

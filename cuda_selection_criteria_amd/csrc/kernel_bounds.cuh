@@ -67,10 +67,20 @@ __device__ __forceinline__ void cb_bounds_body(int i, const double* __restrict__
     }
 }
 
+// the counter blocks of the NEXT pass (the other of the context's two sets) are cleared by the first kernel of this one
+__device__ __forceinline__ void zero_next_counters(int t, int n_threads, PassCounters* __restrict__ zero_pc, int n_blocks) {
+    if (!zero_pc) return;
+    u64* w = reinterpret_cast<u64*>(zero_pc);
+    const int words = n_blocks * (int)(sizeof(PassCounters) / 8);
+    for (int j = t; j < words; j += n_threads) w[j] = 0;
+}
+
 __global__ void cb_bounds_kernel(const double* __restrict__ cards, int n, double tau, int use_cb,
                                  RowMap rm, u64* __restrict__ ecard, int* __restrict__ hi,
-                                 PassCounters* __restrict__ pc, int* __restrict__ csr_zero, int cand_begin) {
-    cb_bounds_body((int)(blockIdx.x * blockDim.x + threadIdx.x), cards, n, tau, use_cb, rm, ecard, hi, pc, csr_zero, cand_begin);
+                                 PassCounters* __restrict__ pc, int* __restrict__ csr_zero, int cand_begin, PassCounters* __restrict__ zero_pc) {
+    const int t = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    zero_next_counters(t, (int)(gridDim.x * blockDim.x), zero_pc, kCounterBlocks);
+    cb_bounds_body(t, cards, n, tau, use_cb, rm, ecard, hi, pc, csr_zero, cand_begin);
 }
 
 }  // namespace

@@ -131,21 +131,24 @@ void csr_fill_kernel(const selhip_int2_t* __restrict__ pairs, const u64* __restr
     }
 }
 
-// exclusive scan of the per-row counts for small N: one 1024-thread block, thread t owns the contiguous slice
-// [t*E, (t+1)*E), E = ceil(N/1024) <= 32 -- one launch instead of the two of rocprim::exclusive_scan (look-back state
-// init + scan); larger N goes to rocPRIM.
-constexpr int kSmallScanMax = 32768;
+constexpr int kSmallScanMax = 32768;        // rows whose counts one block scans in LDS (128 KiB); larger N: rocPRIM scan + csr_fill_kernel
+
+// csr_scan_fill_kernel: the two grouping steps in ONE launch for n <= kSmallScanMax: every block repeats the exclusive scan of
+// the per-row counts into its own LDS copy (n ints; a few microseconds, all blocks at once) and then scatters its share of the
+// pairs -- one dispatch and one single-block kernel less on the stream than scan + fill.
 __global__ __launch_bounds__(1024)
-void csr_scan_small_kernel(const int* __restrict__ cnt, int* __restrict__ start, int n) {
+void csr_scan_fill_kernel(const int* __restrict__ cnt, int n, const selhip_int2_t* __restrict__ pairs, const u64* __restrict__ n_dev,
+                          u64 cap, int* __restrict__ fill, selhip_int2_t* __restrict__ grouped) {
+    extern __shared__ int csr_start_lds[];                                  // n ints
     __shared__ int wave_sum[16];
     const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
-    const int per = (n + 1023) / 1024;
+    const int per = (n + 1023) / 1024;                                      // <= 32
     const int i0 = threadIdx.x * per, i1 = min(i0 + per, n);
     int v[32];
     int mine = 0;
 #pragma unroll
     for (int t = 0; t < 32; ++t) { v[t] = (t < per && i0 + t < i1) ? cnt[i0 + t] : 0; mine += v[t]; }
-    int inc = mine;                                                         // inclusive scan inside the wave
+    int inc = mine;
 #pragma unroll
     for (int s = 1; s < kWave; s <<= 1) { const int o = __shfl_up(inc, s, kWave); if (lane >= s) inc += o; }
     if (lane == kWave - 1) wave_sum[wave] = inc;
@@ -153,7 +156,15 @@ void csr_scan_small_kernel(const int* __restrict__ cnt, int* __restrict__ start,
     int run = inc - mine;
     for (int w = 0; w < wave; ++w) run += wave_sum[w];
 #pragma unroll
-    for (int t = 0; t < 32; ++t) { if (t < per && i0 + t < i1) start[i0 + t] = run; run += v[t]; }
+    for (int t = 0; t < 32; ++t) { if (t < per && i0 + t < i1) csr_start_lds[i0 + t] = run; run += v[t]; }
+    __syncthreads();
+    u64 np = *n_dev;
+    if (np > cap) np = cap;
+    for (u64 j = (u64)blockIdx.x * 1024 + threadIdx.x; j < np; j += (u64)gridDim.x * 1024) {
+        const selhip_int2_t pr = pairs[j];
+        const u64 pos = (u64)csr_start_lds[pr.x] + (u64)atomicAdd(&fill[pr.x], 1);
+        if (pos < cap) grouped[pos] = pr;
+    }
 }
 
 // hll_union_hist_runs_kernel (p = 14): one wave per block with a lane-private [bin][lane] histogram (16 KiB of LDS).

@@ -97,9 +97,10 @@ void sig_build_kernel(const u64* __restrict__ aux, int n, int m, int r, int nb, 
                       uint32_t* __restrict__ sigQ, uint32_t* __restrict__ sigT, uint32_t* __restrict__ sigP, uint32_t* __restrict__ sigG,
                       int bounds_blocks, const double* __restrict__ cards, double tau, int use_cb, RowMap rm,
                       u64* __restrict__ ecard, int* __restrict__ hi, PassCounters* __restrict__ pc, int* __restrict__ csr_zero, int cand_begin,
-                      u64* __restrict__ seg_zero, int seg_zero_n, int pk_shift) {
+                      u64* __restrict__ seg_zero, int seg_zero_n, int pk_shift, PassCounters* __restrict__ zero_pc) {
     if ((int)blockIdx.x < bounds_blocks) {
         const int t = (int)(blockIdx.x * kBlock + threadIdx.x);
+        zero_next_counters(t, bounds_blocks * kBlock, zero_pc, kCounterBlocks);
         for (int j = t; j < seg_zero_n; j += bounds_blocks * kBlock) seg_zero[j] = 0;      // the join's append-segment counters of this pass
         cb_bounds_body(t, cards, n, tau, use_cb, rm, ecard, hi, pc, csr_zero, cand_begin);
         return;

@@ -93,6 +93,7 @@ struct KernelTimer {
 };
 
 constexpr int kMaxChunks = 8;
+static_assert(kCounterBlocks == kMaxChunks + 1, "common.cuh: counter blocks per pass");
 constexpr long long kEnumPairs = 1ll << 26;    // hll_a / hll_an as first criterion: pairs listed per sub-pass (512 MiB of int2)
 
 enum { T_PREP = 0, T_STAGE1, T_HIST, T_SELECT, T_TOTAL, T_SIGBUILD, T_JOIN, T_VERIFY, T_AUX, T_GROUP, T_COUNT };
@@ -120,7 +121,9 @@ struct selhip_ctx {
     // derived / scratch
     DevBuf<u64> ecard;
     DevBuf<int> hi;
-    DevBuf<PassCounters> pc;
+    DevBuf<PassCounters> pc;            // TWO sets of kMaxChunks + 1 counter blocks: pass k uses set k & 1 and its first kernel clears the other
+    PassCounters* pcb = nullptr;        // the set of the pass enqueued last
+    int pc_flip = 0;
     DevBuf<u64> seg_cnt;                // the join's append-segment counters: (kMaxChunks + 1) x kAppendSegs x kSegStride
     DevBuf<selhip_int2_t> surv;
     DevBuf<uint32_t> counts;
@@ -148,6 +151,7 @@ struct selhip_ctx {
     int pipeline = -1;                  // -1 auto, 0 off, >0 forced chunk count
     int64_t cand_begin = 0;             // candidates restricted to ranks >= cand_begin (selhip_ctx_set_candidate_begin)
     int il_block = 128, il_parts = 1, il_part = 0;    // row interleave (selhip_ctx_set_row_interleave); il_parts 1 = contiguous
+    int hist_pad = 0;                   // stage 2a: extra LDS bytes per one-wave block (lowers the number of resident waves per CU)
     int hist_run = 1, hist_blocks = kHistSpanBlocks;   // stage 2a: pairs per task, one-wave blocks (multiple of 8)
     int verify_fb = 0;                  // test hook: force the collision fallback of verify16_kernel
     int join_wpb = 4;                   // 16-bit join: waves per block (DPP form: 1 or 4; LDS form: 4 or 8 -- the waves of a block share the staged query tile)
@@ -266,7 +270,7 @@ hipError_t launch_stream(selhip_ctx* c, const StageIO& io, int row_begin, int ro
     const long long blocks = (long long)n_tiles * n_chunks;
     if (blocks > 0x7FFFFFFFll) return hipErrorInvalidValue;
     hipLaunchKernelGGL((smh_stream_kernel<NCH, LOG2R>), dim3((unsigned)blocks), dim3(kBlock), 0, io.st,
-                       reinterpret_cast<const u64x2*>(c->aux_il.p), n, c->hi.p, c->pc.p,
+                       reinterpret_cast<const u64x2*>(c->aux_il.p), n, c->hi.p, c->pcb,
                        rm, n_tiles, chunk_base, io.surv, io.cap, io.pc);
     return hipGetLastError();
 }
@@ -303,7 +307,7 @@ hipError_t launch_stage1(selhip_ctx* c, const StageIO& io, int n_rows, int n_ban
     if (blocks <= 0) return hipSuccess;
     if (blocks > 0x7FFFFFFFll) return hipErrorInvalidValue;
     hipLaunchKernelGGL(smh_generic_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, io.st,
-                       c->d_aux, n, c->m, n_rows, n_bands, c->hi.p, c->pc.p, rm, (int)rows,
+                       c->d_aux, n, c->m, n_rows, n_bands, c->hi.p, c->pcb, rm, (int)rows,
                        io.surv, io.cap, io.pc);
     return hipGetLastError();
 }
@@ -331,7 +335,7 @@ hipError_t launch_join(selhip_ctx* c, const StageIO& io, int n_pad, int rb, int 
     const long long blocks = (long long)n_tiles * n_gblocks;
     if (blocks > 0x7FFFFFFFll) return hipErrorInvalidValue;
     hipLaunchKernelGGL((sig_join_kernel<NB>), dim3((unsigned)blocks), dim3(kBlock), 0, io.st,
-                       c->sigT.p, n, n_pad, c->hi.p, c->pc.p, rm, n_tiles, group_base, qt,
+                       c->sigT.p, n, n_pad, c->hi.p, c->pcb, rm, n_tiles, group_base, qt,
                        io.cand, io.cap, io.pc);
     return hipGetLastError();
 }
@@ -352,7 +356,7 @@ hipError_t launch_join16_w(selhip_ctx* c, const StageIO& io, int n_pad, int rb, 
     const long long blocks = (long long)n_tiles * n_gblocks;
     if (blocks > 0x7FFFFFFFll) return hipErrorInvalidValue;
     hipLaunchKernelGGL((sig16_join_kernel<ND, DB, WPB>), dim3((unsigned)blocks), dim3(WPB * kWave), 0, io.st,
-                       c->sigP.p, n, n_pad, c->hi.p, c->pc.p, rm, n_tiles, group_base, qt,
+                       c->sigP.p, n, n_pad, c->hi.p, c->pcb, rm, n_tiles, group_base, qt,
                        io.cand, io.cap, io.seg_cnt);
     return hipGetLastError();
 }
@@ -380,11 +384,11 @@ hipError_t launch_joinl_w(selhip_ctx* c, const StageIO& io, int n_pad, int rb, i
     if (smem > 64 * 1024) return hipErrorInvalidValue;                                   // join_qt is capped so that this cannot happen
     if (c->join_bits == 15)
         hipLaunchKernelGGL((sigl_join_kernel<ND, T, WPB, true>), dim3((unsigned)blocks), dim3(WPB * kWave), smem, io.st,
-                           c->sigP.p, c->sigG.p, n, n_pad, c->hi.p, c->pc.p, rm, n_tiles, group_base, qt,
+                           c->sigP.p, c->sigG.p, n, n_pad, c->hi.p, c->pcb, rm, n_tiles, group_base, qt,
                            io.cand, io.cap, io.seg_cnt);
     else
         hipLaunchKernelGGL((sigl_join_kernel<ND, T, WPB, false>), dim3((unsigned)blocks), dim3(WPB * kWave), smem, io.st,
-                           c->sigP.p, c->sigG.p, n, n_pad, c->hi.p, c->pc.p, rm, n_tiles, group_base, qt,
+                           c->sigP.p, c->sigG.p, n, n_pad, c->hi.p, c->pcb, rm, n_tiles, group_base, qt,
                            io.cand, io.cap, io.seg_cnt);
     return hipGetLastError();
 }
@@ -403,7 +407,7 @@ hipError_t launch_join16(selhip_ctx* c, const StageIO& io, int n_pad, int rb, in
 }
 
 // sig_build with the pass's bounds computation riding in its first blocks (with_bounds) or alone
-hipError_t launch_sig_build(selhip_ctx* c, int n_rows, int n_bands, bool with_bounds, double tau, int rb, int re) {
+hipError_t launch_sig_build(selhip_ctx* c, int n_rows, int n_bands, bool with_bounds, double tau, int rb, int re, PassCounters* zero_pc) {
     const int n = (int)c->n;
     const int n_pad = ((n + kWave - 1) / kWave) * kWave;
     TimerScope t(c, T_SIGBUILD);
@@ -411,9 +415,10 @@ hipError_t launch_sig_build(selhip_ctx* c, int n_rows, int n_bands, bool with_bo
     const int bounds_blocks = with_bounds ? (n + kBlock - 1) / kBlock : 0;
     hipLaunchKernelGGL(sig_build_kernel, dim3((unsigned)((threads + kBlock - 1) / kBlock) + (unsigned)bounds_blocks), dim3(kBlock), 0, c->stream,
                        c->d_aux, n, c->m, n_rows, n_bands, n_pad, c->sigQ.p, c->sigT.p, c->sigP.p, c->sigG.p,
-                       bounds_blocks, c->d_cards, tau, c->mode == SELHIP_MODE_CB_SMH ? 1 : 0, row_map(c, rb, re), c->ecard.p, c->hi.p, c->pc.p,
+                       bounds_blocks, c->d_cards, tau, c->mode == SELHIP_MODE_CB_SMH ? 1 : 0, row_map(c, rb, re), c->ecard.p, c->hi.p, c->pcb,
                        (c->p == 14 && c->group_stage2) ? c->csr_cnt.p : nullptr, (int)c->cand_begin,
-                       with_bounds ? c->seg_cnt.p : nullptr, with_bounds ? (int)c->seg_cnt.cap : 0, c->join_bits == 15 ? 17 : 16);
+                       with_bounds ? c->seg_cnt.p : nullptr, with_bounds ? (int)c->seg_cnt.cap : 0, c->join_bits == 15 ? 17 : 16,
+                       zero_pc);
     return hipGetLastError();
 }
 
@@ -477,7 +482,7 @@ hipError_t launch_stage1_hashjoin(selhip_ctx* c, const StageIO& io, int n_rows, 
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(run_emit_kernel, dim3(grid_for((u64)total, kBlock, 8192)), dim3(kBlock), 0, io.st,
                        c->hj_keys_out.p, c->hj_vals_out.p, total, c->sigQ.p, n_bands, c->d_aux, c->m, n_rows, n_bands,
-                       n, c->hi.p, c->pc.p, row_map(c, rb, re), io.surv, io.cap, io.pc);
+                       n, c->hi.p, c->pcb, row_map(c, rb, re), io.surv, io.cap, io.pc);
     return hipGetLastError();
 }
 
@@ -597,7 +602,6 @@ int enqueue_pass(selhip_ctx* c) {
     const int rb = (int)c->row_begin, re = (int)c->row_end;
     const double tau = (double)c->tau_f;            // float threshold widened, selection.cpp:81,164
     const int crit = c->criterion;
-    PassCounters* pc0 = c->pc.p;                    // block 0: z0, evaluated, results; blocks 1.. : one per row chunk
     {
         const bool smh = crit == SELHIP_CRIT_SMH_A || crit == SELHIP_CRIT_HLL_A_SMH_A;
         const bool sig = smh && (c->algo == SELHIP_ALGO_HASHJOIN ||
@@ -606,7 +610,6 @@ int enqueue_pass(selhip_ctx* c) {
         if (c->timing) c->timed_passes += 1;
     }
     TimerScope total(c, T_TOTAL);
-    HIPCHK(&c->err, hipMemsetAsync(c->pc.p, 0, sizeof(PassCounters) * (kMaxChunks + 1), c->stream));
     const bool smh_crit = crit == SELHIP_CRIT_SMH_A || crit == SELHIP_CRIT_HLL_A_SMH_A;
     const bool use_hash = smh_crit && c->algo == SELHIP_ALGO_HASHJOIN;
     const bool use_sig = use_hash || (smh_crit && (c->algo == SELHIP_ALGO_SIG || c->algo == SELHIP_ALGO_AUTO) &&
@@ -619,14 +622,21 @@ int enqueue_pass(selhip_ctx* c) {
         set_err(&c->err, "ALGO_HASHJOIN needs power-of-two rows (got %d x %d)", c->n_rows, c->n_bands);
         return SELHIP_E_BADARG;
     }
+    // counter set of this pass (block 0: z0, evaluated, results; blocks 1.. : one per row chunk); the other set is cleared by
+    // this pass's first kernel for the next pass -- no memset dispatch on the stream.  (Chosen only now: nothing above launches, and
+    // an argument error must not consume a set that no kernel has cleared.)
+    c->pcb = c->pc.p + (size_t)c->pc_flip * (kMaxChunks + 1);
+    PassCounters* const pc_next = c->pc.p + (size_t)(c->pc_flip ^ 1) * (kMaxChunks + 1);
+    c->pc_flip ^= 1;
+    PassCounters* pc0 = c->pcb;
     if (use_sig) {
         // bounds (truncated cards, CB cut-offs, z0, evaluated count) ride in the first blocks of the signature build
-        HIPCHK(&c->err, launch_sig_build(c, c->n_rows, c->n_bands, true, tau, rb, re));
+        HIPCHK(&c->err, launch_sig_build(c, c->n_rows, c->n_bands, true, tau, rb, re, pc_next));
     } else {
         TimerScope t(c, T_PREP);
         hipLaunchKernelGGL(cb_bounds_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream,
                            c->d_cards, n, tau, c->mode == SELHIP_MODE_CB_SMH ? 1 : 0, row_map(c, rb, re), c->ecard.p, c->hi.p, pc0,
-                           (c->p == 14 && c->group_stage2) ? c->csr_cnt.p : nullptr, (int)c->cand_begin);
+                           (c->p == 14 && c->group_stage2) ? c->csr_cnt.p : nullptr, (int)c->cand_begin, pc_next);
         HIPCHK(&c->err, hipGetLastError());
         if (smh_crit && stream_supported(c->m, c->n_rows)) {
             // ALGO_STREAM: the bucket-interleaved copy of the sketches (lane l = buckets [l*B, (l+1)*B)), rebuilt every pass
@@ -675,7 +685,7 @@ int enqueue_pass(selhip_ctx* c) {
         }
         HIPCHK(&c->err, hipEventRecord(c->ev_end, c->st_stage2));          // stage 2 of the last chunk waited for all of stage 1
         HIPCHK(&c->err, hipStreamWaitEvent(c->stream, c->ev_end, 0));
-        HIPCHK(&c->err, hipMemcpyAsync(c->h_pc, c->pc.p, sizeof(PassCounters) * (kMaxChunks + 1), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(&c->err, hipMemcpyAsync(c->h_pc, c->pcb, sizeof(PassCounters) * (kMaxChunks + 1), hipMemcpyDeviceToHost, c->stream));
         return SELHIP_OK;
     }
 
@@ -759,23 +769,26 @@ int enqueue_pass(selhip_ctx* c) {
                 HIPCHK(&c->err, hipGetLastError());
             }
             if (n <= kSmallScanMax) {
-                hipLaunchKernelGGL(csr_scan_small_kernel, dim3(1), dim3(1024), 0, c->stream, c->csr_cnt.p, c->csr_start.p, n);
+                if ((size_t)n * sizeof(int) > 48 * 1024)       // per device, so not cached in a process-wide flag (selhip_multi_select drives several)
+                    HIPCHK(&c->err, hipFuncSetAttribute((const void*)csr_scan_fill_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kSmallScanMax * 4));
+                hipLaunchKernelGGL(csr_scan_fill_kernel, dim3(256), dim3(1024), (size_t)n * sizeof(int), c->stream, c->csr_cnt.p, n,
+                                   final_list, final_count, final_cap, c->csr_cnt.p + n, c->grouped.p);
                 HIPCHK(&c->err, hipGetLastError());
             } else {
                 size_t tmp_bytes = c->scan_tmp.cap;
                 HIPCHK(&c->err, rocprim::exclusive_scan(c->scan_tmp.p, tmp_bytes, c->csr_cnt.p, c->csr_start.p, 0, (size_t)n,
                                                         rocprim::plus<int>(), c->stream));
+                hipLaunchKernelGGL(csr_fill_kernel, dim3(512), dim3(kBlock), 0, c->stream, final_list, final_count, final_cap,
+                                   c->csr_start.p, c->csr_cnt.p + n, c->grouped.p);
+                HIPCHK(&c->err, hipGetLastError());
             }
-            hipLaunchKernelGGL(csr_fill_kernel, dim3(512), dim3(kBlock), 0, c->stream, final_list, final_count, final_cap,
-                               c->csr_start.p, c->csr_cnt.p + n, c->grouped.p);
-            HIPCHK(&c->err, hipGetLastError());
             final_list = c->grouped.p;
         }
         for (u64 off = 0; off < final_cap; off += window) {
             {
                 TimerScope t(c, T_HIST);
                 if (c->p == 14)
-                    hipLaunchKernelGGL(hll_union_hist_runs_kernel, dim3(c->hist_blocks), dim3(kWave), 0, c->stream,
+                    hipLaunchKernelGGL(hll_union_hist_runs_kernel, dim3(c->hist_blocks), dim3(kWave), (size_t)c->hist_pad, c->stream,
                                        c->d_hll, final_list, final_count, final_cap, c->counts.p, off, window, c->hist_run);
                 else
                     hipLaunchKernelGGL(hll_union_hist_kernel, dim3(2048), dim3(kBlock), 0, c->stream,
@@ -788,14 +801,20 @@ int enqueue_pass(selhip_ctx* c) {
                                              c->results.p, (u64)c->results.cap, pc0, nullptr, nullptr, off, window));
         }
     }
-    HIPCHK(&c->err, hipMemcpyAsync(c->h_pc, c->pc.p, sizeof(PassCounters) * (kMaxChunks + 1), hipMemcpyDeviceToHost, c->stream));
+    // (handing the counters to the host from the last block of the final kernel instead of this copy was tried: the 1 024
+    // "block done" atomics on one address cost 16 us, the copy dispatch 4)
+    HIPCHK(&c->err, hipMemcpyAsync(c->h_pc, c->pcb, sizeof(PassCounters) * (kMaxChunks + 1), hipMemcpyDeviceToHost, c->stream));
     return SELHIP_OK;
 }
 
 int ensure_scratch(selhip_ctx* c, size_t surv_cap, size_t res_cap) {
     HIPCHK(&c->err, c->ecard.ensure((size_t)c->n));
     HIPCHK(&c->err, c->hi.ensure((size_t)c->n));
-    HIPCHK(&c->err, c->pc.ensure(kMaxChunks + 1));
+    if (!c->pc.p) {
+        HIPCHK(&c->err, c->pc.ensure(2 * (kMaxChunks + 1)));
+        HIPCHK(&c->err, hipMemsetAsync(c->pc.p, 0, sizeof(PassCounters) * 2 * (kMaxChunks + 1), c->stream));
+        c->pc_flip = 0;
+    }
     HIPCHK(&c->err, c->seg_cnt.ensure((size_t)(kMaxChunks + 1) * kAppendSegs * kSegStride));
     if (!c->st_stage1) {
         HIPCHK(&c->err, hipStreamCreateWithFlags(&c->st_stage1, hipStreamNonBlocking));
@@ -973,6 +992,11 @@ int selhip_ctx_set_param(selhip_ctx* c, const char* name, int value) {
     if (!std::strcmp(name, "hist_run")) {
         if (value < 1 || value > 1024) { set_err(&c->err, "hist_run must be in [1, 1024]"); return SELHIP_E_BADARG; }
         c->hist_run = value;
+        return SELHIP_OK;
+    }
+    if (!std::strcmp(name, "hist_pad")) {
+        if (value < 0 || value > 48 * 1024) { set_err(&c->err, "hist_pad must be in [0, 49152]"); return SELHIP_E_BADARG; }
+        c->hist_pad = value;
         return SELHIP_OK;
     }
     if (!std::strcmp(name, "hist_blocks")) {
@@ -1252,7 +1276,7 @@ int selhip_ctx_copy_results_framed(selhip_ctx* c, void* d_dst, int64_t cap_recor
     if (!c || !d_dst || cap_records < 0) return SELHIP_E_BADARG;
     if (!c->have_run) return SELHIP_E_STATE;
     HIPCHK(&c->err, hipSetDevice(c->device));
-    HIPCHK(&c->err, hipMemcpyAsync(d_dst, &c->pc.p->n_results, sizeof(u64), hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(&c->err, hipMemcpyAsync(d_dst, &c->pcb->n_results, sizeof(u64), hipMemcpyDeviceToDevice, c->stream));
     const int64_t cnt = std::min<int64_t>((int64_t)c->last.n_results, cap_records);
     if (cnt > 0)
         HIPCHK(&c->err, hipMemcpyAsync((char*)d_dst + sizeof(selhip_pair_t), c->results.p, (size_t)cnt * sizeof(selhip_pair_t),
@@ -1263,11 +1287,11 @@ int selhip_ctx_copy_results_framed(selhip_ctx* c, void* d_dst, int64_t cap_recor
 int selhip_ctx_copy_results_framed_async(selhip_ctx* c, void* d_dst, int64_t cap_records) {
     if (!c || !d_dst || cap_records < 0) return SELHIP_E_BADARG;
     if (!c->pending && !c->have_run) return SELHIP_E_STATE;
-    if (!c->results.p || !c->pc.p) return SELHIP_E_STATE;
+    if (!c->results.p || !c->pcb) return SELHIP_E_STATE;
     HIPCHK(&c->err, hipSetDevice(c->device));
     if ((uintptr_t)d_dst & 15) { set_err(&c->err, "frame buffer must be 16-byte aligned"); return SELHIP_E_BADARG; }
     static_assert(sizeof(selhip_pair_t) == 16, "frame records are 16 bytes");
-    hipLaunchKernelGGL(frame_results_kernel, dim3(256), dim3(kBlock), 0, c->stream, c->results.p, &c->pc.p->n_results,
+    hipLaunchKernelGGL(frame_results_kernel, dim3(256), dim3(kBlock), 0, c->stream, c->results.p, &c->pcb->n_results,
                        (u64)c->results.cap, (u64)cap_records, (uint4*)d_dst);
     HIPCHK(&c->err, hipGetLastError());
     return SELHIP_OK;
