@@ -1,5 +1,5 @@
 #!/bin/bash
-# GPU box: PMC passes over join_probe.py for the variants given as "Q WPB T QT" strings; prints per-kernel averages of the join
+# GPU box: PMC passes over join_probe.py for the variants given as "Q WPB QT" strings; prints per-kernel averages of the join
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 WL=$1; shift
 mkdir -p $R/gpurun_out/r02
