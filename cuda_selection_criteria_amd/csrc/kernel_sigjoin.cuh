@@ -364,14 +364,14 @@ __device__ __forceinline__ void joinl_reset15(uint32_t (&acc)[T][4]) {
 
 template <int T>
 __device__ __forceinline__ void joinl_test15(const uint32_t (&acc)[T][4], int i, int k0, int lane, int z0, int n,
-                                             const int* __restrict__ hi, WaveAppender& app) {
+                                             const int* hi_rows, int r, WaveAppender& app) {
 #pragma unroll
     for (int t = 0; t < T; ++t) {
         const uint32_t f = (acc[t][0] & acc[t][1]) & (acc[t][2] & acc[t][3]) & 0x80008000u;
         const u64 mm = __ballot(f != 0x80008000u);
         if (mm) {
             const int lo = max(i + 1, z0);
-            const int hk = min(hi[i], n - 1);
+            const int hk = min(hi_rows[r], n - 1);
             const int k = k0 + t * kWave;
             app.push(((mm >> lane) & 1ull) && k >= lo && k <= hk, i, k, lane);
         }
@@ -386,9 +386,11 @@ __device__ __forceinline__ void joinl_reset(us2_t (&acc)[T][4]) {
         for (int a = 0; a < 4; ++a) acc[t][a] = us2_t{0xFFFF, 0xFFFF};
 }
 
+// (a hit reads the row's CB cut-off from the block's LDS copy: a global load here stalled the wave for a memory round trip on the
+//  ~6 % of rows that have a 16-bit match somewhere in the wave)
 template <int T>
 __device__ __forceinline__ void joinl_test(const us2_t (&acc)[T][4], int i, int k0, int lane, int z0, int n,
-                                           const int* __restrict__ hi, WaveAppender& app) {
+                                           const int* hi_rows, int r, WaveAppender& app) {
 #pragma unroll
     for (int t = 0; t < T; ++t) {
         const uint32_t mv = __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_elementwise_min(acc[t][0], acc[t][1]),
@@ -396,7 +398,7 @@ __device__ __forceinline__ void joinl_test(const us2_t (&acc)[T][4], int i, int 
         const u64 mm = __ballot(min(mv & 0xFFFFu, mv >> 16) == 0u);
         if (mm) {
             const int lo = max(i + 1, z0);
-            const int hk = min(hi[i], n - 1);
+            const int hk = min(hi_rows[r], n - 1);
             const int k = k0 + t * kWave;
             app.push(((mm >> lane) & 1ull) && k >= lo && k <= hk, i, k, lane);
         }
@@ -423,44 +425,31 @@ __global__ __launch_bounds__(WPB * kWave)
 void sigl_join_kernel(const uint32_t* __restrict__ sigP, const uint32_t* __restrict__ sigG, int n, int n_pad,
                       const int* __restrict__ hi, const PassCounters* __restrict__ pc_in,
                       RowMap rm, int n_tiles, int group_base, int qt,
-                      selhip_int2_t* __restrict__ pre, u64 pre_cap, u64* __restrict__ seg_cnt) {
+                      selhip_int2_t* __restrict__ pre, u64 pre_cap, u64* __restrict__ seg_cnt, int cb_pruned) {
     extern __shared__ __attribute__((aligned(16))) uint32_t joinl_smem[];
     selhip_int2_t* const app_lds = reinterpret_cast<selhip_int2_t*>(joinl_smem);                  // WPB * kAppendCap records
-    uint32_t* const tile_lds = joinl_smem + WPB * kAppendCap * 2;                                 // (qt + pad) rows x ND dwords
+    int* const hi_lds = reinterpret_cast<int*>(joinl_smem + WPB * kAppendCap * 2);                // hi[] of the tile's rows
+    uint32_t* const tile_lds = joinl_smem + WPB * kAppendCap * 2 + ((qt + 3) & ~3);               // (qt + pad) rows x ND dwords
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
     const int tile = blockIdx.x % n_tiles;
     const int grp_b = group_base + (blockIdx.x / n_tiles) * (WPB * T);                            // the block's first candidate group
-    // ---- block-uniform part: which rows can meet this block's candidates at all
+    // (walking the candidate blocks from the highest ranks down, so that the grid tapers off on the short columns, was measured:
+    //  cfg3 119 vs 109 us -- kept in ascending order)
+    // ---- block-uniform part, arithmetic only: which rows can meet this block's candidates at all (half of the grid lies below
+    // the diagonal and leaves here without touching memory)
     if (grp_b * kWave >= n) return;
-    const int z0 = pc_in->z0p1 ? pc_in->z0p1 - 1 : n;
     const int kb_last = (grp_b + WPB * T) * kWave - 1;
     int i_lo, i_end;
     rm.tile_rows(tile, qt, &i_lo, &i_end);
     const int ib_hi = min(i_end, kb_last);                                    // need i < k for some lane of the block
-    if (i_lo >= ib_hi || kb_last < z0) return;
-    if (hi[ib_hi - 1] < grp_b * kWave) return;                                // hi is non-decreasing
-    {   // stage the rows [i_lo, ib_hi) of sigG: contiguous, 16-byte aligned (ND is a multiple of 4)
-        const uint4* src = reinterpret_cast<const uint4*>(sigG + (size_t)i_lo * ND);
-        uint4* dst = reinterpret_cast<uint4*>(tile_lds);
-        const int n16 = (ib_hi - i_lo) * (ND / 4);
-        for (int t = threadIdx.x; t < n16; t += WPB * kWave) dst[t] = src[t];
-    }
-    __syncthreads();
-    // ---- per wave (no block-wide synchronisation below)
+    if (i_lo >= ib_hi) return;
+    // (with CB pruning most blocks lie beyond the rows' cut-offs: one dependent load decides that before anything is fetched; in
+    //  the all-pairs mode hi = n-1 everywhere and the test is skipped)
+    if (cb_pruned && hi[ib_hi - 1] < grp_b * kWave) return;                   // hi is non-decreasing
+    // ---- every load of the prologue is issued before anything waits: the wave's candidate signatures, z0, the tile rows and
+    // their CB cut-offs are independent of each other (one memory round trip instead of four in a row at the head of a block)
     const int k_base = (grp_b + wave * T) * kWave;
-    if (k_base >= n) return;
-    const int k_last = k_base + T * kWave - 1;
-    const int i_hi = min(i_end, k_last);
-    if (i_lo >= i_hi || k_last < z0) return;
-    if (hi[i_hi - 1] < k_base) return;
-
-    WaveAppender app;
-    {
-        const int seg = blockIdx.x % kAppendSegs;
-        const u64 seg_cap = pre_cap / kAppendSegs;
-        app.init(app_lds, wave, pre + (size_t)seg * seg_cap, seg_cap, seg_cnt + seg * kSegStride);
-    }
     const int k0 = k_base + lane;
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(sigP), 0, ND * n_pad * 4, 0x00020000);
     const int row_bytes = n_pad * 4;
@@ -471,6 +460,29 @@ void sigl_join_kernel(const uint32_t* __restrict__ sigP, const uint32_t* __restr
 #pragma unroll
         for (int d = 0; d < ND; ++d) c[t][d] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rsrc, kk * 4, d * row_bytes, 0);
     }
+    const int z0p1 = pc_in->z0p1;
+    {   // stage the rows [i_lo, ib_hi) of sigG: contiguous, 16-byte aligned (ND is a multiple of 4)
+        const uint4* src = reinterpret_cast<const uint4*>(sigG + (size_t)i_lo * ND);
+        uint4* dst = reinterpret_cast<uint4*>(tile_lds);
+        const int n16 = (ib_hi - i_lo) * (ND / 4);
+        for (int t = threadIdx.x; t < n16; t += WPB * kWave) dst[t] = src[t];
+        for (int t = threadIdx.x; t < ib_hi - i_lo; t += WPB * kWave) hi_lds[t] = hi[i_lo + t];
+    }
+    __syncthreads();
+    // ---- per wave (no block-wide synchronisation below)
+    const int z0 = z0p1 ? z0p1 - 1 : n;
+    if (k_base >= n) return;
+    const int k_last = k_base + T * kWave - 1;
+    const int i_hi = min(i_end, k_last);
+    if (i_lo >= i_hi || k_last < z0) return;
+    if (hi_lds[i_hi - 1 - i_lo] < k_base) return;                             // hi is non-decreasing
+
+    WaveAppender app;
+    {
+        const int seg = blockIdx.x % kAppendSegs;
+        const u64 seg_cap = pre_cap / kAppendSegs;
+        app.init(app_lds, wave, pre + (size_t)seg * seg_cap, seg_cap, seg_cnt + seg * kSegStride);
+    }
     constexpr int CH = ND < 16 ? ND : 16;                                      // dwords per chunk (one register set)
     constexpr int NCH = ND / CH;                                               // chunks per row: 1 (<= 32 bands), 2 (64), 4 (128)
     const int rows = i_hi - i_lo;
@@ -480,7 +492,7 @@ void sigl_join_kernel(const uint32_t* __restrict__ sigP, const uint32_t* __restr
     asm volatile("" : "+v"(k7));                                               // keep the constant in a VGPR (a literal operand is not a plain VOP2)
 #define SELHIP_JL_RESET()            do { if constexpr (SIG15) joinl_reset15<T>(acc); else joinl_reset<T>(acc); } while (0)
 #define SELHIP_JL_ACCUM(OFF, Q)      do { if constexpr (SIG15) joinl_accum15<ND, T, OFF, CH>(acc, c, Q, k7); else joinl_accum<ND, T, OFF, CH>(acc, c, Q); } while (0)
-#define SELHIP_JL_TEST(I)            do { if constexpr (SIG15) joinl_test15<T>(acc, I, k0, lane, z0, n, hi, app); else joinl_test<T>(acc, I, k0, lane, z0, n, hi, app); } while (0)
+#define SELHIP_JL_TEST(R)            do { if constexpr (SIG15) joinl_test15<T>(acc, i_lo + (R), k0, lane, z0, n, hi_lds, R, app); else joinl_test<T>(acc, i_lo + (R), k0, lane, z0, n, hi_lds, R, app); } while (0)
     uint32_t qa[CH], qb[CH];
     joinl_load<CH>(qa, tile_lds);
     if constexpr (NCH == 1) {
@@ -488,12 +500,12 @@ void sigl_join_kernel(const uint32_t* __restrict__ sigP, const uint32_t* __restr
             joinl_load<CH>(qb, tile_lds + (r + 1) * ND);
             SELHIP_JL_RESET();
             SELHIP_JL_ACCUM(0, qa);
-            SELHIP_JL_TEST(i_lo + r);
+            SELHIP_JL_TEST(r);
             if (r + 1 >= rows) break;
             joinl_load<CH>(qa, tile_lds + (r + 2) * ND);
             SELHIP_JL_RESET();
             SELHIP_JL_ACCUM(0, qb);
-            SELHIP_JL_TEST(i_lo + r + 1);
+            SELHIP_JL_TEST(r + 1);
         }
     } else {
         for (int r = 0; r < rows; ++r) {
@@ -512,7 +524,7 @@ void sigl_join_kernel(const uint32_t* __restrict__ sigP, const uint32_t* __restr
                 joinl_load<CH>(qa, row + ND);
                 SELHIP_JL_ACCUM(3 * CH, qb);
             }
-            SELHIP_JL_TEST(i_lo + r);
+            SELHIP_JL_TEST(r);
         }
     }
 #undef SELHIP_JL_RESET

@@ -366,7 +366,7 @@ hipError_t launch_joinl_w(selhip_ctx* c, const StageIO& io, int n_pad, int rb, i
     const int n = (int)c->n;
     // tile height: the configured one, capped so that the tile (+ appenders) fits 64 KiB of LDS; a multiple of 16 that divides the
     // interleave block when rows are interleaved
-    int qt = std::min(c->join_qt, (int)((64 * 1024 - WPB * kAppendCap * sizeof(selhip_int2_t)) / (ND * 4) - kJoinTilePadRows) / 16 * 16);
+    int qt = std::min(c->join_qt, (int)((64 * 1024 - WPB * kAppendCap * sizeof(selhip_int2_t)) / (ND * 4 + 4) - kJoinTilePadRows) / 16 * 16);
     if (c->il_parts > 1) while (c->il_block % qt) qt -= 16;
     const RowMap rm = row_map(c, rb, re);
     const long long n_tiles_ll = rm.n_tiles(qt);
@@ -380,16 +380,16 @@ hipError_t launch_joinl_w(selhip_ctx* c, const StageIO& io, int n_pad, int rb, i
     if (n_tiles <= 0 || n_gblocks <= 0) return hipSuccess;
     const long long blocks = (long long)n_tiles * n_gblocks;
     if (blocks > 0x7FFFFFFFll) return hipErrorInvalidValue;
-    const size_t smem = (size_t)WPB * kAppendCap * sizeof(selhip_int2_t) + (size_t)(qt + kJoinTilePadRows) * ND * 4;
+    const size_t smem = (size_t)WPB * kAppendCap * sizeof(selhip_int2_t) + (size_t)((qt + 3) & ~3) * 4 + (size_t)(qt + kJoinTilePadRows) * ND * 4;
     if (smem > 64 * 1024) return hipErrorInvalidValue;                                   // join_qt is capped so that this cannot happen
     if (c->join_bits == 15)
         hipLaunchKernelGGL((sigl_join_kernel<ND, T, WPB, true>), dim3((unsigned)blocks), dim3(WPB * kWave), smem, io.st,
                            c->sigP.p, c->sigG.p, n, n_pad, c->hi.p, c->pcb, rm, n_tiles, group_base, qt,
-                           io.cand, io.cap, io.seg_cnt);
+                           io.cand, io.cap, io.seg_cnt, c->mode == SELHIP_MODE_CB_SMH ? 1 : 0);
     else
         hipLaunchKernelGGL((sigl_join_kernel<ND, T, WPB, false>), dim3((unsigned)blocks), dim3(WPB * kWave), smem, io.st,
                            c->sigP.p, c->sigG.p, n, n_pad, c->hi.p, c->pcb, rm, n_tiles, group_base, qt,
-                           io.cand, io.cap, io.seg_cnt);
+                           io.cand, io.cap, io.seg_cnt, c->mode == SELHIP_MODE_CB_SMH ? 1 : 0);
     return hipGetLastError();
 }
 
