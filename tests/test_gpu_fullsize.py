@@ -40,6 +40,24 @@ def test_baseline_configs_bit_exact_vs_oracle(oracle, key):
                 assert st["evaluated"] == 49_995_000 and len(want) == 45_000               # 1000 clusters x C(10,2)
 
 
+def test_grouping_scan_in_lds_above_64k(oracle):
+    """17 000 genomes: the survivors' per-row counts are scanned in every block's LDS by csr_scan_fill_kernel with a 68 KB dynamic
+    allocation (above the 64 KB default limit, below the 32 768-row switch to the rocPRIM scan) -- the sizes the weak-scaling bench
+    reaches at 4 and 8 GPUs (20 000 / 28 280 genomes); bit-exact against the oracle"""
+    from cuda_selection_criteria_amd.synth import SynthConfig
+    cfg = SynthConfig("n17000", 17_000, 128, 0.9, 0x5EED0044)
+    hll_t, aux_t, cards_t, _, _ = pkg.synth_device(cfg)
+    hll, aux, cards = fetch_np(hll_t, aux_t, cards_t)
+    r, b = pkg.banding(cfg.m, cfg.tau)
+    want, st = oracle.select(hll, aux, cards, cfg.tau, r, b, use_cb=False, threads=16)
+    with Selector(0) as sel:
+        sel.attach(hll_t, aux_t, cards_t)
+        got = sel.run(cfg.tau, MODE_SMH, r, b)
+        assert same(got, want) and len(got) > 10_000
+        s = sel.stats()
+        assert s["evaluated"] == st["evaluated"] and s["survivors"] == st["survivors"]
+
+
 def test_config4_scale_properties():
     """50 000 genomes, m=512 (configs[3]; 1.25e9 pairs -- beyond the oracle's reach in a test): properties only"""
     cfg = pkg.SYNTH_CONFIGS["cfg4"]
