@@ -157,7 +157,7 @@ def hip_lib():
     """libselhip.so, loaded lazily.  Raises (never falls back) if it has not been built."""
     global _hip
     if _hip is None:
-        path = LIB_DIR / "libselhip.so"
+        path = Path(os.environ.get("SELHIP_LIB", LIB_DIR / "libselhip.so"))      # SELHIP_LIB: development A/B builds of the same library
         if not path.exists():
             raise ImportError(f"{path} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                               f"or `make -C {_PKG / 'csrc'}` -- there is no CPU fallback")

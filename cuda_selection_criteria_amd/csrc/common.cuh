@@ -11,7 +11,14 @@ constexpr int kWave = 64;
 constexpr int kBlock = 256;            // 4 waves
 constexpr int kWavesPerBlock = kBlock / kWave;
 constexpr int kChunk = 256;            // candidates per stage-1 block
-constexpr int kQueryVgprBudget = 28;   // u64x2 query registers per lane  (Q * NCH): 112 VGPRs + the candidate double buffer fit 168 without scratch
+#ifndef SELHIP_QBUDGET
+#define SELHIP_QBUDGET 24
+#endif
+#ifndef SELHIP_AHEAD
+#define SELHIP_AHEAD 2
+#endif
+constexpr int kQueryVgprBudget = SELHIP_QBUDGET;   // u64x2 query registers per lane  (Q * NCH): 96 VGPRs + the ring of candidate registers fit 168 without scratch
+constexpr int kStreamAhead = SELHIP_AHEAD;        // ALGO_STREAM: candidate rows in flight ahead of the one being compared
 
 // ---------------------------------------------------------------------------------------------
 // device-side counters of one pass

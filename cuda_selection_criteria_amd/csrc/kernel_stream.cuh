@@ -77,7 +77,7 @@ __device__ __forceinline__ bool stream_band_pass(const u64x2 (&cand)[NCH], const
 // smh_stream_kernel<NCH, LOG2R>: m = 128*NCH buckets, bands of 2^LOG2R rows.
 //   block  = 4 waves; one block = (query tile of Q = 28/NCH rows) x (chunk of kChunk candidates)
 //   LDS    = the Q query sketches (28 KiB), staged once per block with coalesced 16-B loads, then copied to VGPRs by each wave
-//   stream = each wave walks its candidates (stride 4), NCH x global_load_dwordx4 (1 KiB each) per candidate, one candidate ahead
+//   stream = each wave walks its candidates (stride 4), NCH x global_load_dwordx4 (1 KiB each) per candidate, kStreamAhead candidates ahead
 // blockIdx.x -> (tile = b % n_tiles, chunk = b / n_tiles): blocks b and b+8 (same XCD under round-robin
 // dispatch) work on the same candidate chunk, so the chunk is served by that XCD's L2.
 // Registers: Q*NCH = 28 query + 2*NCH candidate u64x2 (112 + 32 VGPRs at NCH = 4): no scratch under the 168-VGPR cap of
@@ -131,28 +131,38 @@ void smh_stream_kernel(const u64x2* __restrict__ aux, int n,
     if (k >= k_end) return;
     WaveAppender app;
     app.init(app_lds, wave, surv, surv_cap, &pc->n_survivors);
-    // software pipeline: the next candidate's loads are in flight while the current one is compared
-    u64x2 cand[NCH], nxt[NCH];
-    {
-        const u64x2* row = aux + (long long)k * ROWV + lane;
+    // software pipeline: kStreamAhead candidates' loads are in flight while one is compared -- a ring of kStreamAhead + 1 register
+    // sets, the loop unrolled over the ring so that every set is addressed statically
+    constexpr int AHEAD = NCH <= 4 ? kStreamAhead : 1;                         // (m >= 1024: the registers allow one row ahead)
+    constexpr int RING = AHEAD + 1;
+    u64x2 ring[RING][NCH];
+    auto load_row = [&](u64x2 (&dst)[NCH], int kk) {
+        const int kc = min(kk, k_end - 1);                                    // clamped: prefetches past the end re-read a valid row
+        const u64x2* row = aux + (long long)kc * ROWV + lane;
 #pragma unroll
-        for (int c = 0; c < NCH; ++c) nxt[c] = row[c * kWave];
-    }
-    for (; k < k_end; k += kWavesPerBlock) {
-#pragma unroll
-        for (int c = 0; c < NCH; ++c) cand[c] = nxt[c];
-        {
-            const int kn = min(k + kWavesPerBlock, k_end - 1);                // clamped: last prefetch re-reads a valid row
-            const u64x2* row = aux + (long long)kn * ROWV + lane;
-#pragma unroll
-            for (int c = 0; c < NCH; ++c) nxt[c] = row[c * kWave];
-        }
+        for (int c = 0; c < NCH; ++c) dst[c] = row[c * kWave];
+    };
+    auto compare_row = [&](const u64x2 (&cand)[NCH], int kk) {
 #pragma unroll
         for (int a = 0; a < Q; ++a) {
             if (stream_band_pass<NCH, LOG2R>(cand, q[a])) {
+                // (the empty volatile asm pins the branch on the band mask alone: merged with the range tests below, the compiler
+                //  spent 10 scalar instructions per pair on a condition that is false for all but ~1 pair in 1 000)
+                asm volatile("");
                 const int i = i0 + a;
-                if (i < i_end && k > i && k >= z0 && k <= hi[i]) app.push_uniform(i, k, lane);
+                if (i < i_end && kk > i && kk >= z0 && kk <= hi[i]) app.push_uniform(i, kk, lane);
             }
+        }
+    };
+#pragma unroll
+    for (int s = 0; s < AHEAD; ++s) load_row(ring[s], k + s * kWavesPerBlock);
+    for (; k < k_end; k += RING * kWavesPerBlock) {
+#pragma unroll
+        for (int s = 0; s < RING; ++s) {
+            const int kk = k + s * kWavesPerBlock;
+            if (kk >= k_end) break;
+            load_row(ring[(s + AHEAD) % RING], kk + AHEAD * kWavesPerBlock);
+            compare_row(ring[s], kk);
         }
     }
     app.flush(lane);

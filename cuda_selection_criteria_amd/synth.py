@@ -126,7 +126,7 @@ def harden(aux, frac: float = 0.25, alphabet: int = 2, seed: int = 0xD15EA5E) ->
 
 def stream_model(m: int, n_rows: int) -> dict:
     """instruction counts of smh_stream_kernel per (query, candidate) pair, from its ISA (csrc/kernel_stream.cuh): lane l owns
-    B = m/64 contiguous buckets; B v_cmp_eq_u64; B-1 s_and_b64 (r >= B: + 2 per shift-AND step over r/B lanes); 8 scalar
+    B = m/64 contiguous buckets; B v_cmp_eq_u64; B-1 s_and_b64 (r >= B: + 2 per shift-AND step over r/B lanes); 2 scalar
     instructions for the test and the branch"""
     B = max(2, m // 64)
     steps = 0
@@ -134,4 +134,4 @@ def stream_model(m: int, n_rows: int) -> dict:
     while L > 1:
         steps += 1
         L //= 2
-    return {"valu_wave_instr_per_pair": B, "salu_per_pair": (B - 1) + 2 * steps + 8, "buckets_per_lane": B}
+    return {"valu_wave_instr_per_pair": B, "salu_per_pair": (B - 1) + 2 * steps + 2, "buckets_per_lane": B}

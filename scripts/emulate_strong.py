@@ -1,0 +1,41 @@
+#!/usr/bin/env python3
+"""development: per-rank step time of a STRONG-scaled workload (cfg4 / cfg5 sharded over `world` ranks), emulated on one GPU by
+running each rank's interleaved share in turn; prints the slowest rank and the implied scaling efficiency against the 1-rank step"""
+import sys, time
+from pathlib import Path
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+import torch
+import cuda_selection_criteria_amd as pkg
+wl = sys.argv[1] if len(sys.argv) > 1 else "cfg4"
+worlds = [int(x) for x in sys.argv[2:]] or [2, 4, 8]
+cfg = pkg.SYNTH_CONFIGS[wl]
+hll, aux, cards, _, ah = pkg.synth_device(cfg)
+r, b = pkg.banding(cfg.m, cfg.tau)
+sel = pkg.Selector(0); sel.attach(hll, aux, cards)
+if cfg.p_aux:
+    sel.attach_aux_hll(ah, cfg.p_aux); sel.set_criterion(pkg.CRIT_HLL_A_SMH_A)
+n = cfg.n_genomes
+def timeit(k=10):
+    for _ in range(2): sel.run(cfg.tau, pkg.MODE_SMH, r, b, fetch=False)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(k): sel.run(cfg.tau, pkg.MODE_SMH, r, b, fetch=False)
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / k
+one = timeit()
+print(wl, "1 rank: %.3f ms" % (one * 1e3), flush=True)
+for world in worlds:
+    worst = 0
+    for part in range(world):
+        sel.set_row_interleave(128, world, part)
+        worst = max(worst, timeit())
+    sel.set_row_interleave(0, 1, 0)
+    print(wl, "world %d: slowest rank %.3f ms -> speed-up %.2f (efficiency %.0f %%)" % (world, worst * 1e3, one / worst, 100 * one / worst / world), flush=True)
+# kernel breakdown of one rank's share at the largest world size
+world = worlds[-1]
+sel.set_row_interleave(128, world, world // 2)
+for _ in range(2): sel.run(cfg.tau, pkg.MODE_SMH, r, b, fetch=False)
+sel.timing(1)
+for _ in range(5): sel.run(cfg.tau, pkg.MODE_SMH, r, b, fetch=False)
+print(wl, "world %d part %d kernels (us):" % (world, world // 2), {k: round(sel.kernel_ms(k) * 1e3, 1) for k in ("sigbuild", "join", "verify", "aux", "group", "hist", "select", "total") if sel.kernel_ms(k) > 0}, flush=True)
+sel.timing(0)
