@@ -90,6 +90,71 @@ __device__ __forceinline__ void sig_build_body(long long block, const u64* __res
     }
 }
 
+// sig_build_tile_body: the same signatures, built kSigTileG genomes per block (power-of-two m and nb <= 128, 2 <= r <= 32).
+//  * a thread takes TWO buckets per 16-byte load and four loads are in flight per thread before the first is hashed (the
+//    one-bucket-per-thread form above left ~4 short-lived waves per SIMD waiting on one 8-byte load each: 18 us for 41 MB);
+//  * the band sums are formed with DPP row shifts over the r/2 lanes of a band as before, but land in an LDS tile
+//    [genome][band], from which all four layouts are written in full segments: sigQ / sigG rows contiguous, sigT / sigP as
+//    kSigTileG consecutive genomes per band (the per-genome form wrote each band-major entry as a lone 4-byte store: 19.5 MB
+//    of HBM writes for 7.7 MB of signatures, PMC WRITE_SIZE).
+constexpr int kSigTileG = 16;
+
+__device__ __forceinline__ void sig_build_tile_body(int tile, const u64* __restrict__ aux, int n, int m, int r, int nb, int n_pad,
+                                                    uint32_t* __restrict__ sigQ, uint32_t* __restrict__ sigT, uint32_t* __restrict__ sigP,
+                                                    uint32_t* __restrict__ sigG, int pk_shift) {
+    __shared__ uint32_t sig_lds[kSigTileG][129];                          // pitch 129: the band-major read-out is conflict-free
+    const int g0 = tile * kSigTileG;
+    const int ng = min(kSigTileG, n - g0);
+    if (ng <= 0) return;
+    const int lr = __builtin_ctz((unsigned)r), lm = __builtin_ctz((unsigned)m);
+    const int half_m = m >> 1;                                            // bucket pairs per genome
+    const int total = ng * half_m;                                        // bucket pairs of this tile
+    const u64x2* src = reinterpret_cast<const u64x2*>(aux + (size_t)g0 * m);
+    const int L = r >> 1;                                                 // lanes per band (1..16)
+    for (int base = 0; base < total; base += 4 * kBlock) {
+        u64x2 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int idx = base + u * kBlock + (int)threadIdx.x;
+            v[u] = idx < total ? src[idx] : u64x2{0, 0};
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int idx = base + u * kBlock + (int)threadIdx.x;         // blocks of 256 pairs never straddle a band (L <= 16 divides 256)
+            const int bucket = (idx << 1) & (m - 1);
+            const int j = bucket & (r - 1);                               // position of the first of the two buckets inside its band
+            const u64 x0 = mix64(v[u].x + 0x9E3779B97F4A7C15ull * (u64)(j + 1));
+            const u64 x1 = mix64(v[u].y + 0x9E3779B97F4A7C15ull * (u64)(j + 2));
+            uint32_t hl = (uint32_t)x0 + (uint32_t)x1, hh = (uint32_t)(x0 >> 32) + (uint32_t)(x1 >> 32);
+            if (L > 1) { hl += dpp_row_shr<1>(hl); hh += dpp_row_shr<1>(hh); }
+            if (L > 2) { hl += dpp_row_shr<2>(hl); hh += dpp_row_shr<2>(hh); }
+            if (L > 4) { hl += dpp_row_shr<4>(hl); hh += dpp_row_shr<4>(hh); }
+            if (L > 8) { hl += dpp_row_shr<8>(hl); hh += dpp_row_shr<8>(hh); }
+            if (idx < total && (j + 2) == r) sig_lds[idx >> (lm - 1)][bucket >> lr] = hl ^ hh;      // the band's last lane holds the sums
+        }
+    }
+    __syncthreads();
+    uint16_t* const sigG16 = reinterpret_cast<uint16_t*>(sigG);
+    const int ndw = (nb + 1) >> 1;
+    for (int idx = threadIdx.x; idx < ng * nb; idx += kBlock) {            // genome-major: rows contiguous
+        const int gl = idx / nb, b = idx - gl * nb;
+        const uint32_t sig = sig_lds[gl][b];
+        sigQ[(size_t)(g0 + gl) * nb + b] = sig;
+        sigG16[(size_t)(g0 + gl) * (2 * ndw) + b] = (uint16_t)(sig >> pk_shift);
+    }
+    for (int idx = threadIdx.x; idx < nb * kSigTileG; idx += kBlock) {     // band-major: kSigTileG consecutive genomes per band
+        const int b = idx / kSigTileG, gl = idx - b * kSigTileG;
+        if (gl < ng) sigT[(size_t)b * n_pad + g0 + gl] = sig_lds[gl][b];
+    }
+    for (int idx = threadIdx.x; idx < ndw * kSigTileG; idx += kBlock) {
+        const int d = idx / kSigTileG, gl = idx - d * kSigTileG;
+        if (gl < ng) {
+            const uint32_t lo = sig_lds[gl][2 * d] >> pk_shift, hi2 = (2 * d + 1 < nb) ? (sig_lds[gl][2 * d + 1] >> pk_shift) : 0u;
+            sigP[(size_t)d * n_pad + g0 + gl] = (lo & 0xFFFFu) | (hi2 << 16);
+        }
+    }
+}
+
 // One launch for the two kernels every signature pass starts with: the first `bounds_blocks` blocks run cb_bounds_body (a few
 // waves of binary searches, latency-bound), the others build the signatures -- the bounds then cost nothing on the stream.
 __global__ __launch_bounds__(kBlock)
@@ -97,7 +162,7 @@ void sig_build_kernel(const u64* __restrict__ aux, int n, int m, int r, int nb, 
                       uint32_t* __restrict__ sigQ, uint32_t* __restrict__ sigT, uint32_t* __restrict__ sigP, uint32_t* __restrict__ sigG,
                       int bounds_blocks, const double* __restrict__ cards, double tau, int use_cb, RowMap rm,
                       u64* __restrict__ ecard, int* __restrict__ hi, PassCounters* __restrict__ pc, int* __restrict__ csr_zero, int cand_begin,
-                      u64* __restrict__ seg_zero, int seg_zero_n, int pk_shift, PassCounters* __restrict__ zero_pc) {
+                      u64* __restrict__ seg_zero, int seg_zero_n, int pk_shift, PassCounters* __restrict__ zero_pc, int tile_mode) {
     if ((int)blockIdx.x < bounds_blocks) {
         const int t = (int)(blockIdx.x * kBlock + threadIdx.x);
         zero_next_counters(t, bounds_blocks * kBlock, zero_pc, kCounterBlocks);
@@ -105,7 +170,8 @@ void sig_build_kernel(const u64* __restrict__ aux, int n, int m, int r, int nb, 
         cb_bounds_body(t, cards, n, tau, use_cb, rm, ecard, hi, pc, csr_zero, cand_begin);
         return;
     }
-    sig_build_body((long long)blockIdx.x - bounds_blocks, aux, n, m, r, nb, n_pad, sigQ, sigT, sigP, sigG, pk_shift);
+    if (tile_mode) sig_build_tile_body((int)blockIdx.x - bounds_blocks, aux, n, m, r, nb, n_pad, sigQ, sigT, sigP, sigG, pk_shift);
+    else           sig_build_body((long long)blockIdx.x - bounds_blocks, aux, n, m, r, nb, n_pad, sigQ, sigT, sigP, sigG, pk_shift);
 }
 
 // sig_join_kernel<NB>: all-pairs "some band signature equal", entirely on the vector unit.

@@ -159,6 +159,7 @@ struct selhip_ctx {
     int join_bits = 16;                 // signature width of the all-pairs join: 16 (packed min), 15 (LDS form only: flag arithmetic, all plain VOP2) or 32
     int join_q = 1;                     // 16-bit join, query side: 1 = tile staged in LDS, broadcast reads (sigl_join_kernel), 0 = DPP row broadcast (sig16_join_kernel)
     long long enum_pairs = kEnumPairs;  // hll_a / hll_an as first criterion: pairs listed per sub-pass (test hook "enum_pairs")
+    int sig_tile = 1;                   // signature build: tiled form (0 = one thread per bucket, the round-1 kernel)
     int init_cap = 0;                   // test hook: initial capacity of the survivor / candidate lists (0 = sized from the workload)
     int join_qt = 64;                   // query rows per signature-join block (multiple of 16).  With the segmented appends: cfg3 112 / 114 / 127 us at
                                         // 64 / 96 / 128 rows (finer tiles balance the 1 024 SIMDs better), cfg4 2.12 / 2.10 / 2.07 ms, cfg5 8.31 / 8.16 / 8.20 ms
@@ -411,14 +412,17 @@ hipError_t launch_sig_build(selhip_ctx* c, int n_rows, int n_bands, bool with_bo
     const int n = (int)c->n;
     const int n_pad = ((n + kWave - 1) / kWave) * kWave;
     TimerScope t(c, T_SIGBUILD);
-    const long long threads = n_rows <= kWave ? (long long)n * c->m : (long long)n * n_bands;
     const int bounds_blocks = with_bounds ? (n + kBlock - 1) / kBlock : 0;
-    hipLaunchKernelGGL(sig_build_kernel, dim3((unsigned)((threads + kBlock - 1) / kBlock) + (unsigned)bounds_blocks), dim3(kBlock), 0, c->stream,
+    // tiled build (kSigTileG genomes per block, LDS transpose) for the shapes of the all-pairs joins; the per-bucket form otherwise
+    const bool tile_mode = is_pow2(c->m) && is_pow2(n_bands) && n_bands <= 128 && n_rows >= 2 && n_rows <= 32 && c->m >= 4 && c->sig_tile;
+    const long long threads = n_rows <= kWave ? (long long)n * c->m : (long long)n * n_bands;
+    const unsigned work_blocks = tile_mode ? (unsigned)((n + kSigTileG - 1) / kSigTileG) : (unsigned)((threads + kBlock - 1) / kBlock);
+    hipLaunchKernelGGL(sig_build_kernel, dim3(work_blocks + (unsigned)bounds_blocks), dim3(kBlock), 0, c->stream,
                        c->d_aux, n, c->m, n_rows, n_bands, n_pad, c->sigQ.p, c->sigT.p, c->sigP.p, c->sigG.p,
                        bounds_blocks, c->d_cards, tau, c->mode == SELHIP_MODE_CB_SMH ? 1 : 0, row_map(c, rb, re), c->ecard.p, c->hi.p, c->pcb,
                        (c->p == 14 && c->group_stage2) ? c->csr_cnt.p : nullptr, (int)c->cand_begin,
                        with_bounds ? c->seg_cnt.p : nullptr, with_bounds ? (int)c->seg_cnt.cap : 0, c->join_bits == 15 ? 17 : 16,
-                       zero_pc);
+                       zero_pc, tile_mode ? 1 : 0);
     return hipGetLastError();
 }
 
@@ -974,6 +978,7 @@ int selhip_ctx_set_param(selhip_ctx* c, const char* name, int value) {
     }
     if (!std::strcmp(name, "join_db")) { c->join_db = value != 0; return SELHIP_OK; }
     if (!std::strcmp(name, "join_q")) { c->join_q = value != 0; return SELHIP_OK; }
+    if (!std::strcmp(name, "sig_tile")) { c->sig_tile = value != 0; return SELHIP_OK; }
     if (!std::strcmp(name, "enum_pairs")) {
         if (value < 1) { set_err(&c->err, "enum_pairs must be >= 1"); return SELHIP_E_BADARG; }
         c->enum_pairs = value;
