@@ -80,8 +80,12 @@ __device__ __forceinline__ bool stream_band_pass(const u64x2 (&cand)[NCH], const
 //   stream = each wave walks its candidates (stride 4), NCH x global_load_dwordx4 (1 KiB each) per candidate, kStreamAhead candidates ahead
 // blockIdx.x -> (tile = b % n_tiles, chunk = b / n_tiles): blocks b and b+8 (same XCD under round-robin
 // dispatch) work on the same candidate chunk, so the chunk is served by that XCD's L2.
-// Registers: Q*NCH = 28 query + 2*NCH candidate u64x2 (112 + 32 VGPRs at NCH = 4): no scratch under the 168-VGPR cap of
+// Registers: Q*NCH = 24 query + a ring of 3*NCH candidate u64x2 (96 + 48 VGPRs at NCH = 4): no scratch under the 168-VGPR cap of
 // 3 waves per SIMD (round 1 held 32 query registers and spilled 10 VGPRs: 222 MB of scratch writes per launch).
+// Tried and dropped (round 2): the candidate rows shared by the block's four waves through an LDS ring filled by LDS-DMA loads
+// (`global_load_lds_dwordx4`, 8 rows deep, every wave comparing every row with its own 7 queries, LDS reads double-buffered in
+// registers): 4x fewer L2 reads, but one block barrier per candidate row keeps four waves on four SIMDs in lockstep --
+// 1.78 ms against 1.48 ms for this kernel at cfg3 (bit-identical results).
 // ---------------------------------------------------------------------------------------------
 template <int NCH, int LOG2R>
 __global__ __launch_bounds__(kBlock, (NCH <= 4 ? 3 : 2))
