@@ -161,8 +161,10 @@ struct selhip_ctx {
     long long enum_pairs = kEnumPairs;  // hll_a / hll_an as first criterion: pairs listed per sub-pass (test hook "enum_pairs")
     int sig_tile = 1;                   // signature build: tiled form (0 = one thread per bucket, the round-1 kernel)
     int init_cap = 0;                   // test hook: initial capacity of the survivor / candidate lists (0 = sized from the workload)
-    int join_qt = 64;                   // query rows per signature-join block (multiple of 16).  With the segmented appends: cfg3 112 / 114 / 127 us at
-                                        // 64 / 96 / 128 rows (finer tiles balance the 1 024 SIMDs better), cfg4 2.12 / 2.10 / 2.07 ms, cfg5 8.31 / 8.16 / 8.20 ms
+    int join_qt = 0;                    // query rows per signature-join block (multiple of 16); 0 = automatic: 64 rows up to 4.5e8 pairs per pass
+                                        // (30 000 genomes on one GPU), 128 beyond.  With the segmented appends: cfg3 112 / 114 / 127 us at 64 / 96 / 128 rows (finer tiles balance
+                                        // the 1 024 SIMDs better), cfg4 2.12 / 2.10 / 2.07 ms (a block's prologue -- 32 candidate loads per lane,
+                                        // tile staging -- is amortised over more rows), cfg5 8.31 / 8.16 / 8.20 ms
     bool group_stage2 = true;           // bucket survivors by query row before stage 2a (hll_union_hist_runs_kernel)
 
     // last run parameters (for overflow re-runs)
@@ -316,6 +318,14 @@ hipError_t launch_stage1(selhip_ctx* c, const StageIO& io, int n_rows, int n_ban
 
 unsigned grid_for(u64 items, unsigned per_block, unsigned max_blocks);
 
+// tile height of the signature joins: the configured one, or the automatic choice (see selhip_ctx::join_qt)
+int join_tile_rows(const selhip_ctx* c) {
+    const double pairs_here = 0.5 * (double)c->n * (double)c->n / std::max(1, c->il_parts);       // this context's share of the triangle
+    int qt = c->join_qt > 0 ? c->join_qt : (pairs_here >= 4.5e8 ? 128 : 64);
+    if (c->il_parts > 1) { qt = std::min(qt, c->il_block); while (c->il_block % qt) qt -= 16; }
+    return qt;
+}
+
 bool sig_supported(int m, int n_rows, int n_bands) {
     (void)m;
     return is_pow2(n_rows) && (n_bands == 8 || n_bands == 16 || n_bands == 32 || n_bands == 64 || n_bands == 128);
@@ -324,7 +334,7 @@ bool sig_supported(int m, int n_rows, int n_bands) {
 template <int NB>
 hipError_t launch_join(selhip_ctx* c, const StageIO& io, int n_pad, int rb, int re) {
     const int n = (int)c->n;
-    const int qt = c->join_qt;          // query rows per block (multiple of 16)
+    const int qt = join_tile_rows(c);   // query rows per block (multiple of 16)
     const RowMap rm = row_map(c, rb, re);
     const long long n_tiles_ll = rm.n_tiles(qt);
     if (n_tiles_ll > 0x7FFFFFFFll) return hipErrorInvalidValue;
@@ -345,7 +355,7 @@ template <int ND, bool DB, int WPB>
 hipError_t launch_join16_w(selhip_ctx* c, const StageIO& io, int n_pad, int rb, int re) {
     const int n = (int)c->n;
     if ((long long)ND * n_pad * 4 >= (1ll << 31)) return hipErrorInvalidValue;          // 32-bit offsets into the band-major signature array
-    const int qt = c->join_qt;
+    const int qt = join_tile_rows(c);
     const RowMap rm = row_map(c, rb, re);
     const long long n_tiles_ll = rm.n_tiles(qt);
     if (n_tiles_ll > 0x7FFFFFFFll) return hipErrorInvalidValue;
@@ -367,7 +377,7 @@ hipError_t launch_joinl_w(selhip_ctx* c, const StageIO& io, int n_pad, int rb, i
     const int n = (int)c->n;
     // tile height: the configured one, capped so that the tile (+ appenders) fits 64 KiB of LDS; a multiple of 16 that divides the
     // interleave block when rows are interleaved
-    int qt = std::min(c->join_qt, (int)((64 * 1024 - WPB * kAppendCap * sizeof(selhip_int2_t)) / (ND * 4 + 4) - kJoinTilePadRows) / 16 * 16);
+    int qt = std::min(join_tile_rows(c), (int)((64 * 1024 - WPB * kAppendCap * sizeof(selhip_int2_t)) / (ND * 4 + 4) - kJoinTilePadRows) / 16 * 16);
     if (c->il_parts > 1) while (c->il_block % qt) qt -= 16;
     const RowMap rm = row_map(c, rb, re);
     const long long n_tiles_ll = rm.n_tiles(qt);
@@ -957,16 +967,14 @@ int selhip_ctx_set_row_interleave(selhip_ctx* c, int block_rows, int n_parts, in
         set_err(&c->err, "row interleave: block_rows must be a multiple of 32 (>= 32) and 0 <= part < n_parts");
         return SELHIP_E_BADARG;
     }
-    c->il_block = block_rows; c->il_parts = n_parts; c->il_part = part;
-    c->join_qt = std::min(c->join_qt, block_rows);
-    while (block_rows % c->join_qt) c->join_qt -= 16;          // tile height must divide the block (both multiples of 16)
+    c->il_block = block_rows; c->il_parts = n_parts; c->il_part = part;     // (the join's tile height is fitted to the block in join_tile_rows)
     return SELHIP_OK;
 }
 
 int selhip_ctx_set_param(selhip_ctx* c, const char* name, int value) {
     if (!c || !name) return SELHIP_E_BADARG;
     if (!std::strcmp(name, "join_qt")) {
-        if (value < 16 || value > 4096 || value % 16) { set_err(&c->err, "join_qt must be a multiple of 16 in [16, 4096]"); return SELHIP_E_BADARG; }
+        if (value != 0 && (value < 16 || value > 4096 || value % 16)) { set_err(&c->err, "join_qt must be 0 (automatic) or a multiple of 16 in [16, 4096]"); return SELHIP_E_BADARG; }
         c->join_qt = value;
         return SELHIP_OK;
     }

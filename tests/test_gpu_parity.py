@@ -275,11 +275,11 @@ def test_join_and_histogram_variants(oracle):
                 cand = s["candidates"] if cand is None else cand
                 assert s["candidates"] == cand          # the 32-bit candidate set is the same whichever join produced it
             sel.set_param("join_bits", 16); sel.set_param("join_db", 1); sel.set_param("verify_fb", 0); sel.set_param("join_wpb", 4)
-            sel.set_param("join_q", 1); sel.set_param("join_qt", 64)
+            sel.set_param("join_q", 1); sel.set_param("join_qt", 0)
             for run, blocks in ((1, 8), (3, 64), (8, 2048), (1024, 16384), (1, 16384)):
                 sel.set_param("hist_run", run); sel.set_param("hist_blocks", blocks)
                 assert_same_pairs(sel.run(tau, MODE_CB_SMH, r, b), want)
-            for bad in (("join_bits", 24), ("join_wpb", 2), ("init_cap", -1), ("hist_blocks", 12), ("hist_run", 0), ("no_such_param", 1)):
+            for bad in (("join_bits", 24), ("join_qt", 24), ("join_wpb", 2), ("init_cap", -1), ("hist_blocks", 12), ("hist_run", 0), ("no_such_param", 1)):
                 with pytest.raises(pkg.SelhipError):
                     sel.set_param(*bad)
 
