@@ -136,13 +136,21 @@ int selhip_ctx_set_row_interleave(selhip_ctx* ctx, int block_rows, int n_parts, 
  * rows [0, |I|) and k_min = |I| evaluates exactly the pairs I x J (the out-of-core driver below).  Reset to 0 by upload/attach. */
 int selhip_ctx_set_candidate_begin(selhip_ctx* ctx, int64_t k_min);
 /* Tunables (integers by name; results never depend on them):
- *   "join_qt"     query rows per block of the signature join (multiple of 16, default 128)
+ *   "join_q"      query side of the 16-bit signature join: 1 (default) = tile of query rows staged in LDS, broadcast LDS reads
+ *                 (sigl_join_kernel); 0 = DPP row broadcast from registers (sig16_join_kernel, the round-1 form)
+ *   "join_qt"     query rows per block of the signature join: 0 (default) = automatic (64 below 4.5e8 pairs per pass, 128
+ *                 beyond), or a multiple of 16
  *   "join_bits"   16 (default): all-pairs join on 16-bit band signatures packed two per dword, its matches cut back to the
- *                 32-bit candidate set during verification; 32: join on the 32-bit signatures directly
- *   "join_db"     1 (default) / 0: double-buffered query batches in the 16-bit join
- *   "join_wpb"    waves per block of the 16-bit join: 1 (default) or 4
- *   "hist_run"    pairs a wave of stage 2a takes at a time (default 1);  "hist_blocks"  its one-wave blocks (multiple of 8)
- *   "verify_fb"   test hook: 1 sends every candidate through the hash-collision fallback of the verification */
+ *                 32-bit candidate set during verification; 15: the same with 15-bit signatures and flag arithmetic made of
+ *                 plain VOP2 instructions only (LDS form); 32: join on the 32-bit signatures directly
+ *   "join_db"     1 (default) / 0: double-buffered query batches in the DPP form of the 16-bit join
+ *   "join_wpb"    waves per block of the 16-bit join: LDS form 4 (default) or 8, DPP form 1 or 4
+ *   "sig_tile"    1 (default): signature build 16 genomes per block with an LDS transpose; 0: one thread per bucket
+ *   "hist_run"    pairs a wave of stage 2a takes at a time (default 1);  "hist_blocks"  its one-wave blocks (multiple of 8);
+ *   "hist_pad"    extra LDS bytes per stage-2a block (lowers the resident waves per CU; measurement knob)
+ *   "verify_fb"   test hook: 1 sends every candidate through the hash-collision fallback of the verification
+ *   "init_cap"    test hook: initial capacity of the candidate / survivor / result lists (they grow and the pass repeats)
+ *   "enum_pairs"  test hook: pairs listed per sub-pass when hll_a / hll_an is the first criterion (default 2^26) */
 int selhip_ctx_set_param(selhip_ctx* ctx, const char* name, int value);
 /* Stage 2 grouping (default on): the pairs that reach the HLL-14 stage are bucketed by query row (counting sort) so
  * that waves running side by side on one XCD share their query row in L2.  0 = off (same kernel, list as produced). */
