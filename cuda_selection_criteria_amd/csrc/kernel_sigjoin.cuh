@@ -484,6 +484,10 @@ __device__ __forceinline__ void joinl_load(uint32_t (&q)[CH], const uint32_t* ro
     }
 }
 
+#ifdef SELHIP_JOIN_TRACE
+// development build only (scripts/join_trace.py): per-wave {start, end} wall-clock ticks, rows compared and hardware id -- a timeline of the join
+__device__ unsigned long long g_join_trace[1 << 17][4];
+#endif
 constexpr int kJoinTilePadRows = 2;        // look-ahead reads past the last staged row stay inside the allocation
 
 template <int ND, int T, int WPB, bool SIG15>
@@ -498,10 +502,16 @@ void sigl_join_kernel(const uint32_t* __restrict__ sigP, const uint32_t* __restr
     uint32_t* const tile_lds = joinl_smem + WPB * kAppendCap * 2 + ((qt + 3) & ~3);               // (qt + pad) rows x ND dwords
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
+#ifdef SELHIP_JOIN_TRACE
+    const unsigned long long trace_t0 = wall_clock64();
+#endif
     const int tile = blockIdx.x % n_tiles;
     const int grp_b = group_base + (blockIdx.x / n_tiles) * (WPB * T);                            // the block's first candidate group
     // (walking the candidate blocks from the highest ranks down, so that the grid tapers off on the short columns, was measured:
-    //  cfg3 119 vs 109 us -- kept in ascending order)
+    //  cfg3 119 vs 109 us -- kept in ascending order.  So was a grid resident all at once with the valid (tile, candidate block)
+    //  units dealt out in equal contiguous shares -- tiles of 16 / 32 / 64 rows double-buffered in LDS, candidates reloaded only when
+    //  the block changes: 122-128 us with 2 048 blocks, 116 us with 4 096, bit-identical -- one barrier and one dependent tile
+    //  fetch per unit cost more than the uneven tail of the plain grid: profiles/r02_join_timeline.txt)
     // ---- block-uniform part, arithmetic only: which rows can meet this block's candidates at all (half of the grid lies below
     // the diagonal and leaves here without touching memory)
     if (grp_b * kWave >= n) return;
@@ -596,6 +606,16 @@ void sigl_join_kernel(const uint32_t* __restrict__ sigP, const uint32_t* __restr
 #undef SELHIP_JL_RESET
 #undef SELHIP_JL_ACCUM
 #undef SELHIP_JL_TEST
+#ifdef SELHIP_JOIN_TRACE
+    if (lane == 0) {
+        const unsigned w = blockIdx.x * WPB + wave;
+        if (w < (1u << 17)) {
+            unsigned hwid;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+            g_join_trace[w][0] = trace_t0; g_join_trace[w][1] = wall_clock64(); g_join_trace[w][2] = (unsigned long long)rows; g_join_trace[w][3] = hwid;
+        }
+    }
+#endif
     app.flush(lane);
 }
 

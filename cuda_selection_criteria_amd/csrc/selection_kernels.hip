@@ -1846,6 +1846,19 @@ int selhip_build_sketches(const uint8_t* d_codes, const int64_t* d_offsets, int6
     return SELHIP_OK;
 }
 
+#ifdef SELHIP_JOIN_TRACE
+int selhip_debug_join_trace(unsigned long long* h_out, int clear) {        // development build only (scripts/join_trace.py)
+    if (clear) {
+        void* p = nullptr;
+        HIPCHK(nullptr, hipGetSymbolAddress(&p, HIP_SYMBOL(g_join_trace)));
+        HIPCHK(nullptr, hipMemset(p, 0, sizeof(unsigned long long) * 4 * (1 << 17)));
+        return SELHIP_OK;
+    }
+    HIPCHK(nullptr, hipMemcpyFromSymbol(h_out, HIP_SYMBOL(g_join_trace), sizeof(unsigned long long) * 4 * (1 << 17)));
+    return SELHIP_OK;
+}
+#endif
+
 int selhip_malloc(void** d_ptr, size_t bytes) {
     if (!d_ptr) return SELHIP_E_BADARG;
     HIPCHK(nullptr, hipMalloc(d_ptr, bytes ? bytes : 1));
