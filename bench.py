@@ -69,7 +69,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip stream_kernel / harder_workload (profiling runs)")
     ap.add_argument("--no-grouping", action="store_true", help="stage 2 without bucketing the survivors by query row")
-    ap.add_argument("--pipeline", type=int, default=-1, help="-1 auto, 0 off, 2..8 row chunks (stage 1 of chunk c+1 overlaps stage 2 of chunk c)")
+    ap.add_argument("--pipeline", type=int, default=-1, help="-1 auto (2 chunk lanes from 3e8 pairs per pass), 0 off, 2..8 row chunks, each a whole chain on one of two streams")
     ap.add_argument("--pcie", action="store_true", help="also time a PCIe-inclusive pass (host buffers -> upload -> run)")
     ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed and run the collectives even with one rank (RCCL smoke test)")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",

@@ -22,9 +22,8 @@ __device__ __forceinline__ bool cb_pred(double tau, u64 e1, u64 e2) {
 
 __device__ __forceinline__ void cb_bounds_body(int i, const double* __restrict__ cards, int n, double tau, int use_cb,
                                                RowMap rm, u64* __restrict__ ecard, int* __restrict__ hi,
-                                               PassCounters* __restrict__ pc, int* __restrict__ csr_zero, int cand_begin) {
+                                               PassCounters* __restrict__ pc, int cand_begin) {
     if (i >= n) return;
-    if (csr_zero) { csr_zero[i] = 0; csr_zero[n + i] = 0; }     // stage 2's per-row counters (count / fill cursors) for this pass
     double c = cards[i];
     u64 e1 = selhip::trunc_card(c);
     ecard[i] = e1;
@@ -77,10 +76,13 @@ __device__ __forceinline__ void zero_next_counters(int t, int n_threads, PassCou
 
 __global__ void cb_bounds_kernel(const double* __restrict__ cards, int n, double tau, int use_cb,
                                  RowMap rm, u64* __restrict__ ecard, int* __restrict__ hi,
-                                 PassCounters* __restrict__ pc, int* __restrict__ csr_zero, int cand_begin, PassCounters* __restrict__ zero_pc) {
+                                 PassCounters* __restrict__ pc, int* __restrict__ csr_zero, int csr_zero_n, int cand_begin,
+                                 PassCounters* __restrict__ zero_pc) {
     const int t = (int)(blockIdx.x * blockDim.x + threadIdx.x);
     zero_next_counters(t, (int)(gridDim.x * blockDim.x), zero_pc, kCounterBlocks);
-    cb_bounds_body(t, cards, n, tau, use_cb, rm, ecard, hi, pc, csr_zero, cand_begin);
+    // stage 2's per-row counters (count / fill cursors, one set per chunk lane) for this pass
+    for (int j = t; j < csr_zero_n; j += (int)(gridDim.x * blockDim.x)) csr_zero[j] = 0;
+    cb_bounds_body(t, cards, n, tau, use_cb, rm, ecard, hi, pc, cand_begin);
 }
 
 }  // namespace

@@ -113,10 +113,50 @@ void hll_union_hist_kernel(const uint8_t* __restrict__ hll, int p,
 // all but one of them (ungrouped list: 188 us instead of 118 us at cfg3).
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kBlock)
-void csr_count_kernel(const selhip_int2_t* __restrict__ pairs, const u64* __restrict__ n_dev, u64 cap, int* __restrict__ cnt) {
+void csr_count_kernel(const selhip_int2_t* __restrict__ pairs, const u64* __restrict__ n_dev, u64 cap, int* __restrict__ cnt,
+                      int* __restrict__ lab, int n_rows_total) {
     u64 n = *n_dev;
     if (n > cap) n = cap;
-    for (u64 j = (u64)blockIdx.x * kBlock + threadIdx.x; j < n; j += (u64)gridDim.x * kBlock) atomicAdd(&cnt[pairs[j].x], 1);
+    for (u64 j = (u64)blockIdx.x * kBlock + threadIdx.x; j < n; j += (u64)gridDim.x * kBlock) {
+        const selhip_int2_t pr = pairs[j];
+        atomicAdd(&cnt[pr.x], 1);
+        if (lab) atomicMax(&lab[pr.y], n_rows_total - pr.x);
+    }
+}
+
+// Locality order of the query rows (sets whose HLL rows do not fit the 256 MiB Infinity Cache).  Bucketing by query row alone
+// leaves the buckets in rank = cardinality order, and similar genomes -- the pairs that reach stage 2 -- have similar but not
+// adjacent ranks: the rows of one cluster come up as candidates again and again, each time long after they left the XCD's
+// 4 MiB L2 (measured, profiles/r02_hist_locality.txt: every pair fetches ~1 row from beyond L2 at cfg3/cfg4, 2 at cfg5, and the
+// kernel then runs at the fabric's 6.5 TB/s; with every cluster contiguous in the list it takes 482 instead of 705 us at cfg4,
+// 2.3 instead of 5.5 ns per pair at cfg5).  So the buckets are laid out by LABEL first: label(i) = the smallest rank that
+// row i is paired with (itself if none is smaller) -- for a clique of similar genomes that is the clique's first member, so
+// the clique's buckets become neighbours and stage 2a's waves, which walk the list in order XCD by XCD, meet each of its
+// rows while it is still in L2.  Any other pair graph only gets a different (still valid) order: results do not depend on it.
+//   lab[k] = max over pairs (i, k) of n - i   (0 = no smaller partner; tallied where the pairs are counted)
+//   csr_label_sum:    gsum[label(i)] += cnt[i]
+//   (exclusive scan of gsum -> gbase, rocPRIM)
+//   csr_label_assign: start[i] = atomicAdd(&gbase[label(i)], cnt[i])     (order of the rows inside a label group: free)
+__device__ __forceinline__ int csr_label_of(const int* __restrict__ lab, int i, int n) {
+    const int v = lab[i];
+    return v ? n - v : i;
+}
+
+__global__ __launch_bounds__(kBlock)
+void csr_label_sum_kernel(const int* __restrict__ cnt, const int* __restrict__ lab, int n, int* __restrict__ gsum) {
+    const int i = (int)(blockIdx.x * kBlock + threadIdx.x);
+    if (i >= n) return;
+    const int c = cnt[i];
+    if (c) atomicAdd(&gsum[csr_label_of(lab, i, n)], c);
+}
+
+__global__ __launch_bounds__(kBlock)
+void csr_label_assign_kernel(const int* __restrict__ cnt, const int* __restrict__ lab, int n, int* __restrict__ gbase,
+                             int* __restrict__ start) {
+    const int i = (int)(blockIdx.x * kBlock + threadIdx.x);
+    if (i >= n) return;
+    const int c = cnt[i];
+    start[i] = c ? atomicAdd(&gbase[csr_label_of(lab, i, n)], c) : 0;
 }
 
 __global__ __launch_bounds__(kBlock)

@@ -161,13 +161,14 @@ __global__ __launch_bounds__(kBlock)
 void sig_build_kernel(const u64* __restrict__ aux, int n, int m, int r, int nb, int n_pad,
                       uint32_t* __restrict__ sigQ, uint32_t* __restrict__ sigT, uint32_t* __restrict__ sigP, uint32_t* __restrict__ sigG,
                       int bounds_blocks, const double* __restrict__ cards, double tau, int use_cb, RowMap rm,
-                      u64* __restrict__ ecard, int* __restrict__ hi, PassCounters* __restrict__ pc, int* __restrict__ csr_zero, int cand_begin,
+                      u64* __restrict__ ecard, int* __restrict__ hi, PassCounters* __restrict__ pc, int* __restrict__ csr_zero, int csr_zero_n, int cand_begin,
                       u64* __restrict__ seg_zero, int seg_zero_n, int pk_shift, PassCounters* __restrict__ zero_pc, int tile_mode) {
     if ((int)blockIdx.x < bounds_blocks) {
         const int t = (int)(blockIdx.x * kBlock + threadIdx.x);
         zero_next_counters(t, bounds_blocks * kBlock, zero_pc, kCounterBlocks);
         for (int j = t; j < seg_zero_n; j += bounds_blocks * kBlock) seg_zero[j] = 0;      // the join's append-segment counters of this pass
-        cb_bounds_body(t, cards, n, tau, use_cb, rm, ecard, hi, pc, csr_zero, cand_begin);
+        for (int j = t; j < csr_zero_n; j += bounds_blocks * kBlock) csr_zero[j] = 0;      // stage 2's per-row counters, one set per chunk lane
+        cb_bounds_body(t, cards, n, tau, use_cb, rm, ecard, hi, pc, cand_begin);
         return;
     }
     if (tile_mode) sig_build_tile_body((int)blockIdx.x - bounds_blocks, aux, n, m, r, nb, n_pad, sigQ, sigT, sigP, sigG, pk_shift);
@@ -659,7 +660,7 @@ __global__ __launch_bounds__(kVerifyBlock)
 void verify16_kernel(const u64* __restrict__ aux, int m, int n_rows, int n_bands, const uint32_t* __restrict__ sigQ,
                      const selhip_int2_t* __restrict__ pre_all, const u64* __restrict__ seg_cnt, u64 pre_cap,
                      selhip_int2_t* __restrict__ surv, u64 surv_cap, PassCounters* __restrict__ pc, int force_fallback,
-                     int* __restrict__ row_cnt) {
+                     int* __restrict__ row_cnt, int* __restrict__ row_lab, int n) {
     __shared__ selhip_int2_t out_lds[kVerifyBlock];
     __shared__ uint32_t blk_count, blk_cand;
     __shared__ u64 blk_base;
@@ -752,6 +753,7 @@ void verify16_kernel(const u64* __restrict__ aux, int m, int n_rows, int n_bands
             if (dst < surv_cap) {
                 surv[dst] = q;
                 if (row_cnt) atomicAdd(&row_cnt[q.x], 1);                    // stage 2 grouping: survivors per query row, STORED ones only
+                if (row_lab) atomicMax(&row_lab[q.y], n - q.x);              // ... and every row's smallest partner (csr_label_* in kernel_hll.cuh)
             }                                                                //   (like csr_count_kernel: the offsets must stay inside `grouped`)
         }
         __syncthreads();

@@ -93,6 +93,7 @@ struct KernelTimer {
 };
 
 constexpr int kMaxChunks = 8;
+constexpr double kAutoChunkPairs = 3e8;  // pairs per pass from which the automatic setting splits a pass into two chunk lanes
 static_assert(kCounterBlocks == kMaxChunks + 1, "common.cuh: counter blocks per pass");
 constexpr long long kEnumPairs = 1ll << 26;    // hll_a / hll_an as first criterion: pairs listed per sub-pass (512 MiB of int2)
 
@@ -143,6 +144,7 @@ struct selhip_ctx {
     DevBuf<int> csr_cnt, csr_start;        // stage 2 grouping: survivors per query row (cnt[0..n) counts, cnt[n..2n) fill cursors), offsets
     DevBuf<selhip_int2_t> grouped;         //                   the final pair list bucketed by query row
     DevBuf<char> scan_tmp;
+    size_t scan_tmp_stride = 0;         // bytes of rocPRIM scan scratch per chunk
     PassCounters* h_pc = nullptr;       // pinned host mirror of the kMaxChunks + 1 counter blocks
     // stage pipeline: stage 1 of row chunk c+1 (VALU-bound) overlaps stage 2 of chunk c (memory/LDS-bound)
     hipStream_t st_stage1 = nullptr, st_stage2 = nullptr;     // internal non-blocking streams
@@ -152,7 +154,8 @@ struct selhip_ctx {
     int64_t cand_begin = 0;             // candidates restricted to ranks >= cand_begin (selhip_ctx_set_candidate_begin)
     int il_block = 128, il_parts = 1, il_part = 0;    // row interleave (selhip_ctx_set_row_interleave); il_parts 1 = contiguous
     int hist_pad = 0;                   // stage 2a: extra LDS bytes per one-wave block (lowers the number of resident waves per CU)
-    int hist_run = 1, hist_blocks = kHistSpanBlocks;   // stage 2a: pairs per task, one-wave blocks (multiple of 8)
+    int hist_run = 0, hist_blocks = kHistSpanBlocks;   // stage 2a: pairs per task (0 = automatic: 1, or 4 with the label order), one-wave blocks (multiple of 8)
+    int group_label = -1;               // grouping: lay the query-row buckets out by label (kernel_hll.cuh): -1 = automatic (HLL rows beyond kLabelOrderBytes), 0 off, 1 on
     int verify_fb = 0;                  // test hook: force the collision fallback of verify16_kernel
     int join_wpb = 4;                   // 16-bit join: waves per block (DPP form: 1 or 4; LDS form: 4 or 8 -- the waves of a block share the staged query tile)
     int join_db = 1;                    // 16-bit join: double-buffered query batches
@@ -222,6 +225,7 @@ struct StageIO {
     u64 cap;
     PassCounters* pc;
     int* row_cnt = nullptr;     // if set, the producer of `surv` also tallies survivors per query row (stage-2 grouping)
+    int* row_lab = nullptr;     // ... and every row's smallest partner (label order of the grouping)
     u64* seg_cnt = nullptr;     // 16-bit join: this launch's kAppendSegs append counters
 };
 
@@ -259,15 +263,14 @@ RowMap row_map(const selhip_ctx* c, int rb, int re) {
 
 // ---- stage-1 dispatch ------------------------------------------------------------------------
 template <int NCH, int LOG2R>
-hipError_t launch_stream(selhip_ctx* c, const StageIO& io, int row_begin, int row_end) {
+hipError_t launch_stream(selhip_ctx* c, const StageIO& io, const RowMap& rm) {
     constexpr int Q = kQueryVgprBudget / NCH;
     const int n = (int)c->n;
-    const RowMap rm = row_map(c, row_begin, row_end);
     const long long n_tiles_ll = rm.n_tiles(Q);
     if (n_tiles_ll > 0x7FFFFFFFll) return hipErrorInvalidValue;
     const int n_tiles = (int)n_tiles_ll;
     // candidate columns that can matter: k in (row_begin, n)
-    const int chunk_base = ((row_begin + 1) / kChunk) * kChunk;
+    const int chunk_base = ((rm.row_begin + 1) / kChunk) * kChunk;
     const int n_chunks = (n - chunk_base + kChunk - 1) / kChunk;
     if (n_tiles <= 0 || n_chunks <= 0) return hipSuccess;
     const long long blocks = (long long)n_tiles * n_chunks;
@@ -280,9 +283,9 @@ hipError_t launch_stream(selhip_ctx* c, const StageIO& io, int row_begin, int ro
 
 // LOG2R runs over 0 .. log2(m) = log2(128 * NCH)
 template <int NCH, int LOG2R>
-hipError_t launch_stream_r(selhip_ctx* c, const StageIO& io, int l, int rb, int re) {
-    if (l == LOG2R) return launch_stream<NCH, LOG2R>(c, io, rb, re);
-    if constexpr ((1 << LOG2R) < 128 * NCH) return launch_stream_r<NCH, LOG2R + 1>(c, io, l, rb, re);
+hipError_t launch_stream_r(selhip_ctx* c, const StageIO& io, int l, const RowMap& rm) {
+    if (l == LOG2R) return launch_stream<NCH, LOG2R>(c, io, rm);
+    if constexpr ((1 << LOG2R) < 128 * NCH) return launch_stream_r<NCH, LOG2R + 1>(c, io, l, rm);
     return hipErrorInvalidValue;
 }
 
@@ -290,19 +293,18 @@ bool stream_supported(int m, int n_rows) {
     return is_pow2(m) && m >= 128 && m <= 2048 && is_pow2(n_rows) && n_rows <= m;
 }
 
-hipError_t launch_stage1(selhip_ctx* c, const StageIO& io, int n_rows, int n_bands, int rb, int re) {
+hipError_t launch_stage1(selhip_ctx* c, const StageIO& io, int n_rows, int n_bands, const RowMap& rm) {
     if (stream_supported(c->m, n_rows)) {
         const int nch = c->m / 128;
         const int l = ilog2(n_rows);
         switch (nch) {
-            case 1: return launch_stream_r<1, 0>(c, io, l, rb, re);
-            case 2: return launch_stream_r<2, 0>(c, io, l, rb, re);
-            case 4: return launch_stream_r<4, 0>(c, io, l, rb, re);
-            case 8: return launch_stream_r<8, 0>(c, io, l, rb, re);
-            case 16: return launch_stream_r<16, 0>(c, io, l, rb, re);
+            case 1: return launch_stream_r<1, 0>(c, io, l, rm);
+            case 2: return launch_stream_r<2, 0>(c, io, l, rm);
+            case 4: return launch_stream_r<4, 0>(c, io, l, rm);
+            case 8: return launch_stream_r<8, 0>(c, io, l, rm);
+            case 16: return launch_stream_r<16, 0>(c, io, l, rm);
         }
     }
-    const RowMap rm = row_map(c, rb, re);
     const long long rows = rm.n_tiles(1);
     const int n = (int)c->n;
     const int chunks = (n + kBlock - 1) / kBlock;
@@ -332,14 +334,13 @@ bool sig_supported(int m, int n_rows, int n_bands) {
 }
 
 template <int NB>
-hipError_t launch_join(selhip_ctx* c, const StageIO& io, int n_pad, int rb, int re) {
+hipError_t launch_join(selhip_ctx* c, const StageIO& io, int n_pad, const RowMap& rm) {
     const int n = (int)c->n;
     const int qt = join_tile_rows(c);   // query rows per block (multiple of 16)
-    const RowMap rm = row_map(c, rb, re);
     const long long n_tiles_ll = rm.n_tiles(qt);
     if (n_tiles_ll > 0x7FFFFFFFll) return hipErrorInvalidValue;
     const int n_tiles = (int)n_tiles_ll;
-    const int group_base = (std::max(rb + 1, (int)c->cand_begin) / kWave / kWavesPerBlock) * kWavesPerBlock;   // candidates k > row_begin, k >= cand_begin
+    const int group_base = (std::max(rm.row_begin + 1, (int)c->cand_begin) / kWave / kWavesPerBlock) * kWavesPerBlock;   // candidates k > row_begin, k >= cand_begin
     const int n_groups = (n + kWave - 1) / kWave - group_base;
     const int n_gblocks = (n_groups + kWavesPerBlock - 1) / kWavesPerBlock;
     if (n_tiles <= 0 || n_gblocks <= 0) return hipSuccess;
@@ -352,15 +353,14 @@ hipError_t launch_join(selhip_ctx* c, const StageIO& io, int n_pad, int rb, int 
 }
 
 template <int ND, bool DB, int WPB>
-hipError_t launch_join16_w(selhip_ctx* c, const StageIO& io, int n_pad, int rb, int re) {
+hipError_t launch_join16_w(selhip_ctx* c, const StageIO& io, int n_pad, const RowMap& rm) {
     const int n = (int)c->n;
     if ((long long)ND * n_pad * 4 >= (1ll << 31)) return hipErrorInvalidValue;          // 32-bit offsets into the band-major signature array
     const int qt = join_tile_rows(c);
-    const RowMap rm = row_map(c, rb, re);
     const long long n_tiles_ll = rm.n_tiles(qt);
     if (n_tiles_ll > 0x7FFFFFFFll) return hipErrorInvalidValue;
     const int n_tiles = (int)n_tiles_ll;
-    const int group_base = (std::max(rb + 1, (int)c->cand_begin) / kWave / WPB) * WPB;   // candidates k > row_begin, k >= cand_begin
+    const int group_base = (std::max(rm.row_begin + 1, (int)c->cand_begin) / kWave / WPB) * WPB;   // candidates k > row_begin, k >= cand_begin
     const int n_groups = (n + kWave - 1) / kWave - group_base;
     const int n_gblocks = (n_groups + WPB - 1) / WPB;
     if (n_tiles <= 0 || n_gblocks <= 0) return hipSuccess;
@@ -373,19 +373,18 @@ hipError_t launch_join16_w(selhip_ctx* c, const StageIO& io, int n_pad, int rb, 
 }
 
 template <int ND, int T, int WPB>
-hipError_t launch_joinl_w(selhip_ctx* c, const StageIO& io, int n_pad, int rb, int re) {
+hipError_t launch_joinl_w(selhip_ctx* c, const StageIO& io, int n_pad, const RowMap& rm) {
     const int n = (int)c->n;
     // tile height: the configured one, capped so that the tile (+ appenders) fits 64 KiB of LDS; a multiple of 16 that divides the
     // interleave block when rows are interleaved
     int qt = std::min(join_tile_rows(c), (int)((64 * 1024 - WPB * kAppendCap * sizeof(selhip_int2_t)) / (ND * 4 + 4) - kJoinTilePadRows) / 16 * 16);
     if (c->il_parts > 1) while (c->il_block % qt) qt -= 16;
-    const RowMap rm = row_map(c, rb, re);
     const long long n_tiles_ll = rm.n_tiles(qt);
     if (n_tiles_ll > 0x7FFFFFFFll) return hipErrorInvalidValue;
     const int n_tiles = (int)n_tiles_ll;
     if ((long long)ND * n_pad * 4 >= (1ll << 31)) return hipErrorInvalidValue;          // 32-bit offsets into the band-major signature array
     constexpr int GPB = WPB * T;                                                          // candidate groups per block
-    const int group_base = (std::max(rb + 1, (int)c->cand_begin) / kWave / GPB) * GPB;   // candidates k > row_begin, k >= cand_begin
+    const int group_base = (std::max(rm.row_begin + 1, (int)c->cand_begin) / kWave / GPB) * GPB;   // candidates k > row_begin, k >= cand_begin
     const int n_groups = (n + kWave - 1) / kWave - group_base;
     const int n_gblocks = (n_groups + GPB - 1) / GPB;
     if (n_tiles <= 0 || n_gblocks <= 0) return hipSuccess;
@@ -407,14 +406,14 @@ hipError_t launch_joinl_w(selhip_ctx* c, const StageIO& io, int n_pad, int rb, i
 // (T = 2 groups of candidates per wave -- half the LDS reads -- was measured: 130 VGPRs, 3 waves per SIMD, cfg3 157 vs 127 us,
 // cfg4 2.37 vs 2.07 ms; the template keeps the parameter, only T = 1 is instantiated)
 template <int ND>
-hipError_t launch_joinl(selhip_ctx* c, const StageIO& io, int n_pad, int rb, int re) {
-    return c->join_wpb == 8 ? launch_joinl_w<ND, 1, 8>(c, io, n_pad, rb, re) : launch_joinl_w<ND, 1, 4>(c, io, n_pad, rb, re);
+hipError_t launch_joinl(selhip_ctx* c, const StageIO& io, int n_pad, const RowMap& rm) {
+    return c->join_wpb == 8 ? launch_joinl_w<ND, 1, 8>(c, io, n_pad, rm) : launch_joinl_w<ND, 1, 4>(c, io, n_pad, rm);
 }
 
 template <int ND, bool DB>
-hipError_t launch_join16(selhip_ctx* c, const StageIO& io, int n_pad, int rb, int re) {
-    if (c->join_q) return launch_joinl<ND>(c, io, n_pad, rb, re);
-    return c->join_wpb == 1 ? launch_join16_w<ND, DB, 1>(c, io, n_pad, rb, re) : launch_join16_w<ND, DB, 4>(c, io, n_pad, rb, re);
+hipError_t launch_join16(selhip_ctx* c, const StageIO& io, int n_pad, const RowMap& rm) {
+    if (c->join_q) return launch_joinl<ND>(c, io, n_pad, rm);
+    return c->join_wpb == 1 ? launch_join16_w<ND, DB, 1>(c, io, n_pad, rm) : launch_join16_w<ND, DB, 4>(c, io, n_pad, rm);
 }
 
 // sig_build with the pass's bounds computation riding in its first blocks (with_bounds) or alone
@@ -430,14 +429,14 @@ hipError_t launch_sig_build(selhip_ctx* c, int n_rows, int n_bands, bool with_bo
     hipLaunchKernelGGL(sig_build_kernel, dim3(work_blocks + (unsigned)bounds_blocks), dim3(kBlock), 0, c->stream,
                        c->d_aux, n, c->m, n_rows, n_bands, n_pad, c->sigQ.p, c->sigT.p, c->sigP.p, c->sigG.p,
                        bounds_blocks, c->d_cards, tau, c->mode == SELHIP_MODE_CB_SMH ? 1 : 0, row_map(c, rb, re), c->ecard.p, c->hi.p, c->pcb,
-                       (c->p == 14 && c->group_stage2) ? c->csr_cnt.p : nullptr, (int)c->cand_begin,
+                       (c->p == 14 && c->group_stage2) ? c->csr_cnt.p : nullptr, (c->p == 14 && c->group_stage2) ? (int)c->csr_cnt.cap : 0, (int)c->cand_begin,
                        with_bounds ? c->seg_cnt.p : nullptr, with_bounds ? (int)c->seg_cnt.cap : 0, c->join_bits == 15 ? 17 : 16,
                        zero_pc, tile_mode ? 1 : 0);
     return hipGetLastError();
 }
 
 // signature join + exact verification of the query rows [rb, re) (sig_build must have run)
-hipError_t launch_stage1_sig(selhip_ctx* c, const StageIO& io, int n_rows, int n_bands, int rb, int re) {
+hipError_t launch_stage1_sig(selhip_ctx* c, const StageIO& io, int n_rows, int n_bands, const RowMap& rm) {
     const int n = (int)c->n;
     const int n_pad = ((n + kWave - 1) / kWave) * kWave;
     hipError_t e = hipSuccess;
@@ -445,11 +444,11 @@ hipError_t launch_stage1_sig(selhip_ctx* c, const StageIO& io, int n_rows, int n
         {
             TimerScope t(c, T_JOIN, io.st);
             switch (n_bands) {
-                case 8: e = c->join_db ? launch_join16<4, true>(c, io, n_pad, rb, re) : launch_join16<4, false>(c, io, n_pad, rb, re); break;
-                case 16: e = c->join_db ? launch_join16<8, true>(c, io, n_pad, rb, re) : launch_join16<8, false>(c, io, n_pad, rb, re); break;
-                case 32: e = c->join_db ? launch_join16<16, true>(c, io, n_pad, rb, re) : launch_join16<16, false>(c, io, n_pad, rb, re); break;
-                case 64: e = c->join_db ? launch_join16<32, true>(c, io, n_pad, rb, re) : launch_join16<32, false>(c, io, n_pad, rb, re); break;
-                case 128: e = c->join_db ? launch_join16<64, true>(c, io, n_pad, rb, re) : launch_join16<64, false>(c, io, n_pad, rb, re); break;
+                case 8: e = c->join_db ? launch_join16<4, true>(c, io, n_pad, rm) : launch_join16<4, false>(c, io, n_pad, rm); break;
+                case 16: e = c->join_db ? launch_join16<8, true>(c, io, n_pad, rm) : launch_join16<8, false>(c, io, n_pad, rm); break;
+                case 32: e = c->join_db ? launch_join16<16, true>(c, io, n_pad, rm) : launch_join16<16, false>(c, io, n_pad, rm); break;
+                case 64: e = c->join_db ? launch_join16<32, true>(c, io, n_pad, rm) : launch_join16<32, false>(c, io, n_pad, rm); break;
+                case 128: e = c->join_db ? launch_join16<64, true>(c, io, n_pad, rm) : launch_join16<64, false>(c, io, n_pad, rm); break;
                 default: return hipErrorInvalidValue;
             }
         }
@@ -458,16 +457,16 @@ hipError_t launch_stage1_sig(selhip_ctx* c, const StageIO& io, int n_rows, int n
         TimerScope t(c, T_VERIFY, io.st);
         static_assert(1024 % kAppendSegs == 0, "verify16_kernel: the grid is a multiple of the segment count");
         hipLaunchKernelGGL(verify16_kernel, dim3(1024), dim3(kVerifyBlock), 0, io.st, c->d_aux, c->m, n_rows, n_bands, c->sigQ.p,
-                           io.cand, io.seg_cnt, io.cap, io.surv, io.cap, io.pc, c->verify_fb, io.row_cnt);
+                           io.cand, io.seg_cnt, io.cap, io.surv, io.cap, io.pc, c->verify_fb, io.row_cnt, io.row_lab, n);
         return hipGetLastError();
     } else {
         TimerScope t(c, T_JOIN, io.st);
         switch (n_bands) {
-            case 8: e = launch_join<8>(c, io, n_pad, rb, re); break;
-            case 16: e = launch_join<16>(c, io, n_pad, rb, re); break;
-            case 32: e = launch_join<32>(c, io, n_pad, rb, re); break;
-            case 64: e = launch_join<64>(c, io, n_pad, rb, re); break;
-            case 128: e = launch_join<128>(c, io, n_pad, rb, re); break;
+            case 8: e = launch_join<8>(c, io, n_pad, rm); break;
+            case 16: e = launch_join<16>(c, io, n_pad, rm); break;
+            case 32: e = launch_join<32>(c, io, n_pad, rm); break;
+            case 64: e = launch_join<64>(c, io, n_pad, rm); break;
+            case 128: e = launch_join<128>(c, io, n_pad, rm); break;
             default: return hipErrorInvalidValue;
         }
     }
@@ -479,7 +478,7 @@ hipError_t launch_stage1_sig(selhip_ctx* c, const StageIO& io, int n_rows, int n
 }
 
 // sort-based join of the band signatures (sig_build must have run); rows [rb, re)
-hipError_t launch_stage1_hashjoin(selhip_ctx* c, const StageIO& io, int n_rows, int n_bands, int rb, int re) {
+hipError_t launch_stage1_hashjoin(selhip_ctx* c, const StageIO& io, int n_rows, int n_bands, const RowMap& rm) {
     const int n = (int)c->n;
     const int n_pad = ((n + kWave - 1) / kWave) * kWave;
     const long long total = (long long)n * n_bands;
@@ -496,7 +495,7 @@ hipError_t launch_stage1_hashjoin(selhip_ctx* c, const StageIO& io, int n_rows, 
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(run_emit_kernel, dim3(grid_for((u64)total, kBlock, 8192)), dim3(kBlock), 0, io.st,
                        c->hj_keys_out.p, c->hj_vals_out.p, total, c->sigQ.p, n_bands, c->d_aux, c->m, n_rows, n_bands,
-                       n, c->hi.p, c->pcb, row_map(c, rb, re), io.surv, io.cap, io.pc);
+                       n, c->hi.p, c->pcb, rm, io.surv, io.cap, io.pc);
     return hipGetLastError();
 }
 
@@ -558,8 +557,8 @@ long long pair_bound(long long n, long long rb, long long re) {
 }
 
 template <int CRIT>
-hipError_t launch_aux_fused(selhip_ctx* c, const selhip_int2_t* list, const u64* n_dev, u64 cap, u64 bound, double tau,
-                            u64* out_count) {
+hipError_t launch_aux_fused(selhip_ctx* c, hipStream_t st, const selhip_int2_t* list, const u64* n_dev, u64 cap, u64 bound, double tau,
+                            selhip_int2_t* out, u64 out_cap, u64* out_count) {
     const float Z = 1.96f;                                   // z_score, selection.cpp:76
     const float zs_f = Z * sigma_p_of(c->p_aux);             // float * float (criteria_sketch.hpp:29,40)
     const double zs = (double)zs_f;
@@ -567,36 +566,44 @@ hipError_t launch_aux_fused(selhip_ctx* c, const selhip_int2_t* list, const u64*
     const double rs = relerr_scaled_for(c->p_aux);
     const unsigned grid = grid_for(bound, kWave, 32768);
     if (c->fp_mode == SELHIP_FP_FMA)
-        hipLaunchKernelGGL((aux_fused_kernel<true, CRIT>), dim3(grid), dim3(kWave), 0, c->stream, c->d_aux_hll, c->p_aux, list, n_dev, cap,
-                           rs, c->ecard.p, tau, zs, S_sum, c->fin.p, (u64)c->fin.cap, out_count);
+        hipLaunchKernelGGL((aux_fused_kernel<true, CRIT>), dim3(grid), dim3(kWave), 0, st, c->d_aux_hll, c->p_aux, list, n_dev, cap,
+                           rs, c->ecard.p, tau, zs, S_sum, out, out_cap, out_count);
     else
-        hipLaunchKernelGGL((aux_fused_kernel<false, CRIT>), dim3(grid), dim3(kWave), 0, c->stream, c->d_aux_hll, c->p_aux, list, n_dev, cap,
-                           rs, c->ecard.p, tau, zs, S_sum, c->fin.p, (u64)c->fin.cap, out_count);
+        hipLaunchKernelGGL((aux_fused_kernel<false, CRIT>), dim3(grid), dim3(kWave), 0, st, c->d_aux_hll, c->p_aux, list, n_dev, cap,
+                           rs, c->ecard.p, tau, zs, S_sum, out, out_cap, out_count);
     return hipGetLastError();
 }
 
 // equal-pair row boundaries of the triangle rows [rb, re) x columns (row, n): the same cut the multi-GPU drivers use
-void chunk_rows(long long n, long long rb, long long re, int chunks, long long* bnd) {
+void chunk_rows(long long n, long long rb, long long re, int chunks, long long period, long long* bnd) {
+    // boundaries fall on whole interleave periods counted from rb (row ownership is defined relative to the range's first row)
     const double total = (double)pair_bound(n, rb, re);
     bnd[0] = rb;
     long long i = rb;
     double acc = 0;
     for (int c = 1; c < chunks; ++c) {
         const double target = total * c / chunks;
-        while (i < re && acc < target) { acc += (double)(n - 1 - i); ++i; }
+        while (i < re && acc < target) {
+            const long long e = std::min(re, i + period);
+            acc += (double)pair_bound(n, i, e);
+            i = e;
+        }
         bnd[c] = i;
     }
     bnd[chunks] = re;
 }
 
 int pipeline_chunks(const selhip_ctx* c) {
-    if (c->criterion != SELHIP_CRIT_SMH_A) return 1;
-    // Measured on MI355X (gpurun_out/bench_pipe_*.json): overlapping the two stages does NOT pay --
-    // cfg3 0.61 -> 0.74 / 0.85 ms with 2 / 4 chunks, cfg4 5.05 -> 5.11 / 5.14 ms: the join (VALU issue) and the
-    // histogram kernel (VALU + LDS atomics + memory) contend for the same issue slots, and every chunk adds launches.
-    // So the automatic setting is OFF; the mechanism stays for workloads with a heavier memory-bound stage 2.
-    if (c->pipeline <= 1 || c->il_parts > 1) return 1;
-    return std::min(c->pipeline, kMaxChunks);
+    // Round 1's pipeline (stage 1 of every chunk on one stream, stage 2 on another) lost on every configuration and was replaced
+    // by whole-chain lanes (enqueue_pass).  Automatic setting: two chunks for the signature join once a pass is large enough for
+    // the second set of tail launches to cost less than the overlap wins (measured: profiles/r02_chunk_lanes.txt).
+    const bool smh = c->criterion == SELHIP_CRIT_SMH_A || c->criterion == SELHIP_CRIT_HLL_A_SMH_A;
+    if (!smh || c->pipeline == 0 || c->pipeline == 1 || c->algo == SELHIP_ALGO_HASHJOIN) return 1;   // (the sort join works on all rows at once)
+    if (c->pipeline > 1) return std::min(c->pipeline, kMaxChunks);
+    const bool sig = c->algo != SELHIP_ALGO_STREAM && c->join_bits <= 16 && sig_supported(c->m, c->n_rows, c->n_bands);
+    if (!sig || !(c->p == 14 && c->group_stage2)) return 1;
+    const double pairs = (double)pair_bound(c->n, c->row_begin, c->row_end) / std::max(1, c->il_parts);
+    return pairs >= kAutoChunkPairs ? 2 : 1;
 }
 
 // Wait for the context's stream with low wake-up latency: poll for up to ~2 ms (a pass of the BASELINE single-GPU
@@ -609,6 +616,119 @@ hipError_t wait_stream(hipStream_t st) {
         if (std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) break;
     }
     return hipStreamSynchronize(st);
+}
+
+// one chain of a pass: the stream it runs on, the query rows it covers and its slices of the pass's buffers
+struct Chain {
+    StageIO io;
+    int rb, re;
+    selhip_int2_t* fin; u64 fin_cap;        // output of the auxiliary criterion
+    int* csr_cnt; int* csr_start; char* scan_tmp;
+    selhip_int2_t* grouped;
+    uint32_t* counts; u64 window;           // histogram scratch: `window` pairs at a time
+};
+
+// per-chain row arrays of the grouping: counts | fill cursors | labels | label-group sums (then bucket starts), n ints each
+size_t csr_stride(int n) { return 4 * (size_t)n + 2; }
+
+constexpr double kLabelOrderPairs = 4e8;
+constexpr size_t kLabelOrderBytes = (size_t)192 << 20;     // HLL rows beyond this (the Infinity Cache holds 256 MiB): label order
+bool label_order(const selhip_ctx* c) {
+    if (!(c->p == 14 && c->group_stage2)) return false;
+    if (c->group_label >= 0) return c->group_label == 1;
+    // its three extra launches (~15 us) only pay on a pass with enough pairs in stage 2; the pair space is the proxy known here
+    // (one of 8 ranks of cfg4, 1.6e8 pairs: 0.515 -> 0.529 ms with it; one of 8 ranks of cfg5, 6.2e8: 1.613 -> 1.577 ms)
+    return (size_t)c->n * 16384 > kLabelOrderBytes && (double)pair_bound(c->n, c->row_begin, c->row_end) / std::max(1, c->il_parts) >= kLabelOrderPairs;
+}
+
+// final criterion over a list of pairs: HLL-14 union estimate + Jaccard (selection.cpp:286-288), windows of the counts buffer
+int enqueue_tail(selhip_ctx* c, const Chain& ch, const selhip_int2_t* final_list, const u64* final_count, u64 final_cap,
+                 bool counted, double tau, PassCounters* pc0) {
+    const int n = (int)c->n;
+    hipStream_t st = ch.io.st;
+    const bool grouped = c->p == 14 && c->group_stage2;
+    if (grouped) {
+        // bucket the final list by query row so that stage 2a can keep that row in registers across its pairs
+        TimerScope t(c, T_GROUP, st);
+        // (the counters were cleared by the pass's first kernel)
+        const bool label = label_order(c);
+        int* const cnt = ch.csr_cnt; int* const fill = cnt + n; int* const lab = cnt + 2 * (size_t)n; int* const gsum = cnt + 3 * (size_t)n;
+        if (!counted) {
+            hipLaunchKernelGGL(csr_count_kernel, dim3(512), dim3(kBlock), 0, st, final_list, final_count, final_cap, cnt, label ? lab : nullptr, n);
+            HIPCHK(&c->err, hipGetLastError());
+        }
+        if (label) {
+            const unsigned row_blocks = (unsigned)((n + kBlock - 1) / kBlock);
+            hipLaunchKernelGGL(csr_label_sum_kernel, dim3(row_blocks), dim3(kBlock), 0, st, cnt, lab, n, gsum);
+            HIPCHK(&c->err, hipGetLastError());
+            size_t tmp_bytes = c->scan_tmp_stride;
+            HIPCHK(&c->err, rocprim::exclusive_scan(ch.scan_tmp, tmp_bytes, gsum, ch.csr_start, 0, (size_t)n, rocprim::plus<int>(), st));
+            hipLaunchKernelGGL(csr_label_assign_kernel, dim3(row_blocks), dim3(kBlock), 0, st, cnt, lab, n, ch.csr_start, gsum);   // gsum := bucket starts
+            HIPCHK(&c->err, hipGetLastError());
+            hipLaunchKernelGGL(csr_fill_kernel, dim3(512), dim3(kBlock), 0, st, final_list, final_count, final_cap, gsum, fill, ch.grouped);
+            HIPCHK(&c->err, hipGetLastError());
+        } else if (n <= kSmallScanMax) {
+            if ((size_t)n * sizeof(int) > 48 * 1024)       // per device, so not cached in a process-wide flag (selhip_multi_select drives several)
+                HIPCHK(&c->err, hipFuncSetAttribute((const void*)csr_scan_fill_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kSmallScanMax * 4));
+            hipLaunchKernelGGL(csr_scan_fill_kernel, dim3(256), dim3(1024), (size_t)n * sizeof(int), st, cnt, n,
+                               final_list, final_count, final_cap, fill, ch.grouped);
+            HIPCHK(&c->err, hipGetLastError());
+        } else {
+            size_t tmp_bytes = c->scan_tmp_stride;
+            HIPCHK(&c->err, rocprim::exclusive_scan(ch.scan_tmp, tmp_bytes, cnt, ch.csr_start, 0, (size_t)n, rocprim::plus<int>(), st));
+            hipLaunchKernelGGL(csr_fill_kernel, dim3(512), dim3(kBlock), 0, st, final_list, final_count, final_cap,
+                               ch.csr_start, fill, ch.grouped);
+            HIPCHK(&c->err, hipGetLastError());
+        }
+        final_list = ch.grouped;
+    }
+    for (u64 off = 0; off < final_cap; off += ch.window) {
+        {
+            TimerScope t(c, T_HIST, st);
+            if (c->p == 14)
+                hipLaunchKernelGGL(hll_union_hist_runs_kernel, dim3(c->hist_blocks), dim3(kWave), (size_t)c->hist_pad, st,
+                                   c->d_hll, final_list, final_count, final_cap, ch.counts, off, ch.window,
+                                   c->hist_run > 0 ? c->hist_run : (grouped && label_order(c) ? 4 : 1));
+            else
+                hipLaunchKernelGGL(hll_union_hist_kernel, dim3(2048), dim3(kBlock), 0, st,
+                                   c->d_hll, c->p, final_list, final_count, (u64)0, final_cap, ch.counts, off, ch.window);
+            HIPCHK(&c->err, hipGetLastError());
+        }
+        TimerScope t(c, T_SELECT, st);
+        HIPCHK(&c->err, launch_select<1>(c->fp_mode == SELHIP_FP_FMA, st, 4096, ch.counts, final_count, 0,
+                                         final_cap, c->p, nullptr, final_list, c->ecard.p, tau,
+                                         c->results.p, (u64)c->results.cap, pc0, nullptr, nullptr, off, ch.window));
+    }
+    return SELHIP_OK;
+}
+
+// smh_a (alone or before the auxiliary criterion) over the query rows of one chain, then the final criterion.  [rb, re) is the
+// pass's whole row range (row ownership under the interleave is counted from its first row)
+int enqueue_chain(selhip_ctx* c, const Chain& ch, int rb, int re, double tau, bool use_hash, bool use_sig, bool count_in_verify,
+                  PassCounters* pc0) {
+    const StageIO& io = ch.io;
+    RowMap rm = row_map(c, rb, re);
+    if (c->il_parts <= 1) rm = row_map(c, ch.rb, ch.re);
+    else { rm.row_begin = ch.rb; rm.row_end = ch.re; }          // ch.rb - rb is a multiple of the interleave period
+    {
+        TimerScope t(c, T_STAGE1, io.st);
+        if (use_hash)     HIPCHK(&c->err, launch_stage1_hashjoin(c, io, c->n_rows, c->n_bands, rm));
+        else if (use_sig) HIPCHK(&c->err, launch_stage1_sig(c, io, c->n_rows, c->n_bands, rm));
+        else              HIPCHK(&c->err, launch_stage1(c, io, c->n_rows, c->n_bands, rm));
+    }
+    const selhip_int2_t* final_list = io.surv;
+    const u64* final_count = &io.pc->n_survivors;
+    u64 final_cap = io.cap;
+    if (c->criterion == SELHIP_CRIT_HLL_A_SMH_A) {
+        // two-stage form (BASELINE configs[4]): the auxiliary criterion (histogram + estimator + test fused, one lane per pair)
+        // sees the survivors of the smh_a join
+        TimerScope t(c, T_AUX, io.st);
+        HIPCHK(&c->err, launch_aux_fused<1>(c, io.st, io.surv, &io.pc->n_survivors, io.cap, io.cap, tau, ch.fin, ch.fin_cap, &io.pc->n_final));
+        final_list = ch.fin;
+        final_count = &io.pc->n_final;
+        final_cap = ch.fin_cap;
+    }
+    return enqueue_tail(c, ch, final_list, final_count, final_cap, count_in_verify, tau, pc0);
 }
 
 int enqueue_pass(selhip_ctx* c) {
@@ -650,7 +770,7 @@ int enqueue_pass(selhip_ctx* c) {
         TimerScope t(c, T_PREP);
         hipLaunchKernelGGL(cb_bounds_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream,
                            c->d_cards, n, tau, c->mode == SELHIP_MODE_CB_SMH ? 1 : 0, row_map(c, rb, re), c->ecard.p, c->hi.p, pc0,
-                           (c->p == 14 && c->group_stage2) ? c->csr_cnt.p : nullptr, (int)c->cand_begin, pc_next);
+                           (c->p == 14 && c->group_stage2) ? c->csr_cnt.p : nullptr, (c->p == 14 && c->group_stage2) ? (int)c->csr_cnt.cap : 0, (int)c->cand_begin, pc_next);
         HIPCHK(&c->err, hipGetLastError());
         if (smh_crit && stream_supported(c->m, c->n_rows)) {
             // ALGO_STREAM: the bucket-interleaved copy of the sketches (lane l = buckets [l*B, (l+1)*B)), rebuilt every pass
@@ -664,75 +784,61 @@ int enqueue_pass(selhip_ctx* c) {
 
     const int chunks = pipeline_chunks(c);
     c->n_chunks_last = chunks;
-    if (chunks > 1) {
-        // ---- smh_a, pipelined over row chunks: stage 1 on one stream, stage 2 on another, chained by events.
-        long long bnd[kMaxChunks + 1];
-        chunk_rows(n, rb, re, chunks, bnd);
+    const bool count_in_verify = crit == SELHIP_CRIT_SMH_A && use_sig && !use_hash && c->join_bits <= 16 && c->p == 14 && c->group_stage2;
+    // chunk k's slices of the pass's buffers (one chunk = the whole of each)
+    auto chain_of = [&](int k, hipStream_t st, long long b, long long e) {
         const u64 slice = (u64)c->surv.cap / (u64)chunks;
-        const u64 window = (u64)c->counts.cap / 64;
+        Chain ch;
+        ch.io = StageIO{st, c->cand.p + (size_t)k * slice, c->surv.p + (size_t)k * slice, slice, pc0 + 1 + k};
+        ch.io.seg_cnt = c->seg_cnt.p + (size_t)(1 + k) * kAppendSegs * kSegStride;
+        ch.rb = (int)b; ch.re = (int)e;
+        ch.fin = c->fin.p ? c->fin.p + (size_t)k * ((u64)c->fin.cap / (u64)chunks) : nullptr;
+        ch.fin_cap = (u64)c->fin.cap / (u64)chunks;
+        ch.csr_cnt = c->csr_cnt.p ? c->csr_cnt.p + (size_t)k * csr_stride(n) : nullptr;
+        ch.csr_start = c->csr_start.p ? c->csr_start.p + (size_t)k * ((size_t)n + 2) : nullptr;
+        ch.scan_tmp = c->scan_tmp.p ? c->scan_tmp.p + (size_t)k * c->scan_tmp_stride : nullptr;
+        ch.grouped = c->grouped.p ? c->grouped.p + (size_t)k * slice : nullptr;
+        ch.window = ((u64)c->counts.cap / 64) / (u64)chunks;
+        ch.counts = c->counts.p + (size_t)k * ch.window * 64;
+        if (count_in_verify) { ch.io.row_cnt = ch.csr_cnt; if (label_order(c)) ch.io.row_lab = ch.csr_cnt + 2 * (size_t)n; }
+        return ch;
+    };
+    if (chunks > 1) {
+        // ---- row chunks, each a whole chain (join -> verify -> [auxiliary criterion] -> grouping -> histogram -> estimate) on one of
+        // two streams: while one chunk's short tail kernels (tens of microseconds each, far too few waves to fill the chip) run, the
+        // other chunk's join has the vector units, and the join's own ramp and tail overlap with the neighbour.  Measured with two
+        // contexts on two streams before it was built (scripts/overlap_probe.py): cfg4 on one of 8 ranks 0.551 -> 0.544 ms even with
+        // the signature build done twice.
+        long long bnd[kMaxChunks + 1];
+        chunk_rows(n, rb, re, chunks, c->il_parts > 1 ? (long long)c->il_block * c->il_parts : 1, bnd);
+        // lane 0 is the context's own stream (cross-stream waits cost ~10 us each: one to start lane 1, one to join it)
+        hipStream_t lane[2] = {c->stream, c->st_stage1};
         HIPCHK(&c->err, hipEventRecord(c->ev_start, c->stream));
-        HIPCHK(&c->err, hipStreamWaitEvent(c->st_stage1, c->ev_start, 0));
-        HIPCHK(&c->err, hipStreamWaitEvent(c->st_stage2, c->ev_start, 0));
+        HIPCHK(&c->err, hipStreamWaitEvent(lane[1], c->ev_start, 0));
         for (int k = 0; k < chunks; ++k) {
-            StageIO io{c->st_stage1, c->cand.p + (size_t)k * slice, c->surv.p + (size_t)k * slice, slice, pc0 + 1 + k};
-            io.seg_cnt = c->seg_cnt.p + (size_t)(1 + k) * kAppendSegs * kSegStride;
-            {
-                TimerScope t(c, T_STAGE1, io.st);
-                if (use_hash)     HIPCHK(&c->err, launch_stage1_hashjoin(c, io, c->n_rows, c->n_bands, (int)bnd[k], (int)bnd[k + 1]));
-                else if (use_sig) HIPCHK(&c->err, launch_stage1_sig(c, io, c->n_rows, c->n_bands, (int)bnd[k], (int)bnd[k + 1]));
-                else              HIPCHK(&c->err, launch_stage1(c, io, c->n_rows, c->n_bands, (int)bnd[k], (int)bnd[k + 1]));
-            }
-            HIPCHK(&c->err, hipEventRecord(c->ev_chunk[k], c->st_stage1));
-            HIPCHK(&c->err, hipStreamWaitEvent(c->st_stage2, c->ev_chunk[k], 0));
-            for (u64 off = 0; off < slice; off += window) {
-                {
-                    TimerScope t(c, T_HIST, c->st_stage2);
-                    hipLaunchKernelGGL(hll_union_hist_kernel, dim3(2048), dim3(kBlock), 0, c->st_stage2,
-                                       c->d_hll, c->p, io.surv, &io.pc->n_survivors, (u64)0, slice, c->counts.p, off, window);
-                    HIPCHK(&c->err, hipGetLastError());
-                }
-                TimerScope t(c, T_SELECT, c->st_stage2);
-                HIPCHK(&c->err, launch_select<1>(c->fp_mode == SELHIP_FP_FMA, c->st_stage2, 4096, c->counts.p, &io.pc->n_survivors, 0,
-                                                 slice, c->p, nullptr, io.surv, c->ecard.p, tau,
-                                                 c->results.p, (u64)c->results.cap, pc0, nullptr, nullptr, off, window));
-            }
+            // odd chunks first in program order so that lane 1's work is queued before lane 0's blocks the host thread's view
+            const Chain ch = chain_of(k, lane[(k & 1) ^ 1], bnd[k], bnd[k + 1]);
+            const int rc = enqueue_chain(c, ch, rb, re, tau, use_hash, use_sig, count_in_verify, pc0);
+            if (rc) return rc;
         }
-        HIPCHK(&c->err, hipEventRecord(c->ev_end, c->st_stage2));          // stage 2 of the last chunk waited for all of stage 1
+        HIPCHK(&c->err, hipEventRecord(c->ev_end, lane[1]));
         HIPCHK(&c->err, hipStreamWaitEvent(c->stream, c->ev_end, 0));
         HIPCHK(&c->err, hipMemcpyAsync(c->h_pc, c->pcb, sizeof(PassCounters) * (kMaxChunks + 1), hipMemcpyDeviceToHost, c->stream));
         return SELHIP_OK;
     }
 
     // ---- single chunk: everything in order on the context's stream (counter block 1)
-    StageIO io{c->stream, c->cand.p, c->surv.p, (u64)c->surv.cap, pc0 + 1};
-    io.seg_cnt = c->seg_cnt.p + (size_t)kAppendSegs * kSegStride;
-    // the survivors of the 16-bit signature path are the final list when smh_a is the only criterion: verify16_kernel
-    // then tallies them per query row itself (no csr_count launch)
-    const bool count_in_verify = crit == SELHIP_CRIT_SMH_A && use_sig && !use_hash && c->join_bits <= 16 && c->p == 14 && c->group_stage2;
-    if (count_in_verify) io.row_cnt = c->csr_cnt.p;
-    const selhip_int2_t* final_list = c->surv.p;
-    const u64* final_count = &io.pc->n_survivors;
-    u64 final_cap = (u64)c->surv.cap;
-    if (crit == SELHIP_CRIT_SMH_A || crit == SELHIP_CRIT_HLL_A_SMH_A) {
-        TimerScope t(c, T_STAGE1);
-        if (use_hash)     HIPCHK(&c->err, launch_stage1_hashjoin(c, io, c->n_rows, c->n_bands, rb, re));
-        else if (use_sig) HIPCHK(&c->err, launch_stage1_sig(c, io, c->n_rows, c->n_bands, rb, re));
-        else              HIPCHK(&c->err, launch_stage1(c, io, c->n_rows, c->n_bands, rb, re));
-    }
-    // ---- auxiliary-HLL criterion (hll_a / hll_an): histogram + estimator + test fused, one lane per pair
-    if (crit == SELHIP_CRIT_HLL_A_SMH_A) {
-        // two-stage form (BASELINE configs[4]): the auxiliary criterion sees the survivors of the smh_a join
-        TimerScope t(c, T_AUX);
-        HIPCHK(&c->err, launch_aux_fused<1>(c, c->surv.p, &io.pc->n_survivors, (u64)c->surv.cap, (u64)c->surv.cap, tau, &io.pc->n_final));
-        final_list = c->fin.p;
-        final_count = &io.pc->n_final;
-        final_cap = (u64)c->fin.cap;
-    } else if (crit != SELHIP_CRIT_SMH_A) {
+    const Chain ch = chain_of(0, c->stream, rb, re);
+    if (smh_crit) {
+        const int rc = enqueue_chain(c, ch, rb, re, tau, use_hash, use_sig, count_in_verify, pc0);
+        if (rc) return rc;
+    } else {
         // hll_a / hll_an as FIRST criterion (selection.cpp:152-173, 206-227): the (CB-pruned) pair space of the rows is listed
         // explicitly, kEnumPairs pairs at a time -- row sub-ranges in turn on the stream, each listed into the same buffer and
         // filtered into `fin` before the next one overwrites it (the reference has no limit on N here; round 1 refused
         // more than 2^28 pairs per call).  Sub-range boundaries fall on whole interleave periods so that row ownership
         // (RowMap blocks are counted from the range's first row) is the same as for the whole range.
+        const StageIO& io = ch.io;
         const long long period = c->il_parts > 1 ? (long long)c->il_block * c->il_parts : 1;
         long long sb = rb;
         while (sb < re) {
@@ -762,58 +868,12 @@ int enqueue_pass(selhip_ctx* c) {
             }
             TimerScope t(c, T_AUX);
             const u64 bound = std::min<u64>((u64)c->cand.cap, (u64)acc);
-            if (crit == SELHIP_CRIT_HLL_AN) HIPCHK(&c->err, launch_aux_fused<2>(c, c->cand.p, &io.pc->n_aux_in, (u64)c->cand.cap, bound, tau, &io.pc->n_final));
-            else                            HIPCHK(&c->err, launch_aux_fused<1>(c, c->cand.p, &io.pc->n_aux_in, (u64)c->cand.cap, bound, tau, &io.pc->n_final));
+            if (crit == SELHIP_CRIT_HLL_AN) HIPCHK(&c->err, launch_aux_fused<2>(c, c->stream, c->cand.p, &io.pc->n_aux_in, (u64)c->cand.cap, bound, tau, ch.fin, ch.fin_cap, &io.pc->n_final));
+            else                            HIPCHK(&c->err, launch_aux_fused<1>(c, c->stream, c->cand.p, &io.pc->n_aux_in, (u64)c->cand.cap, bound, tau, ch.fin, ch.fin_cap, &io.pc->n_final));
             sb = se;
         }
-        final_list = c->fin.p;
-        final_count = &io.pc->n_final;
-        final_cap = (u64)c->fin.cap;
-    }
-    // ---- final criterion: HLL-14 union estimate + Jaccard (selection.cpp:286-288), windows of the counts buffer
-    {
-        const u64 window = (u64)c->counts.cap / 64;
-        const bool grouped = c->p == 14 && c->group_stage2;
-        if (grouped) {
-            // bucket the final list by query row so that stage 2a can keep that row in registers across its pairs
-            TimerScope t(c, T_GROUP);
-            // (the counters were cleared by cb_bounds_kernel)
-            if (!count_in_verify) {
-                hipLaunchKernelGGL(csr_count_kernel, dim3(512), dim3(kBlock), 0, c->stream, final_list, final_count, final_cap, c->csr_cnt.p);
-                HIPCHK(&c->err, hipGetLastError());
-            }
-            if (n <= kSmallScanMax) {
-                if ((size_t)n * sizeof(int) > 48 * 1024)       // per device, so not cached in a process-wide flag (selhip_multi_select drives several)
-                    HIPCHK(&c->err, hipFuncSetAttribute((const void*)csr_scan_fill_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kSmallScanMax * 4));
-                hipLaunchKernelGGL(csr_scan_fill_kernel, dim3(256), dim3(1024), (size_t)n * sizeof(int), c->stream, c->csr_cnt.p, n,
-                                   final_list, final_count, final_cap, c->csr_cnt.p + n, c->grouped.p);
-                HIPCHK(&c->err, hipGetLastError());
-            } else {
-                size_t tmp_bytes = c->scan_tmp.cap;
-                HIPCHK(&c->err, rocprim::exclusive_scan(c->scan_tmp.p, tmp_bytes, c->csr_cnt.p, c->csr_start.p, 0, (size_t)n,
-                                                        rocprim::plus<int>(), c->stream));
-                hipLaunchKernelGGL(csr_fill_kernel, dim3(512), dim3(kBlock), 0, c->stream, final_list, final_count, final_cap,
-                                   c->csr_start.p, c->csr_cnt.p + n, c->grouped.p);
-                HIPCHK(&c->err, hipGetLastError());
-            }
-            final_list = c->grouped.p;
-        }
-        for (u64 off = 0; off < final_cap; off += window) {
-            {
-                TimerScope t(c, T_HIST);
-                if (c->p == 14)
-                    hipLaunchKernelGGL(hll_union_hist_runs_kernel, dim3(c->hist_blocks), dim3(kWave), (size_t)c->hist_pad, c->stream,
-                                       c->d_hll, final_list, final_count, final_cap, c->counts.p, off, window, c->hist_run);
-                else
-                    hipLaunchKernelGGL(hll_union_hist_kernel, dim3(2048), dim3(kBlock), 0, c->stream,
-                                       c->d_hll, c->p, final_list, final_count, (u64)0, final_cap, c->counts.p, off, window);
-                HIPCHK(&c->err, hipGetLastError());
-            }
-            TimerScope t(c, T_SELECT);
-            HIPCHK(&c->err, launch_select<1>(c->fp_mode == SELHIP_FP_FMA, c->stream, 4096, c->counts.p, final_count, 0,
-                                             final_cap, c->p, nullptr, final_list, c->ecard.p, tau,
-                                             c->results.p, (u64)c->results.cap, pc0, nullptr, nullptr, off, window));
-        }
+        const int rc = enqueue_tail(c, ch, ch.fin, &io.pc->n_final, ch.fin_cap, false, tau, pc0);
+        if (rc) return rc;
     }
     // (handing the counters to the host from the last block of the final kernel instead of this copy was tried: the 1 024
     // "block done" atomics on one address cost 16 us, the copy dispatch 4)
@@ -876,12 +936,14 @@ int ensure_scratch(selhip_ctx* c, size_t surv_cap, size_t res_cap) {
     HIPCHK(&c->err, c->counts.ensure(std::min<size_t>(std::max(c->surv.cap, (size_t)c->n), (size_t)1 << 20) * 64));
     HIPCHK(&c->err, c->results.ensure(res_cap));
     if (c->group_stage2 && c->p == 14) {
-        HIPCHK(&c->err, c->csr_cnt.ensure(2 * (size_t)c->n + 2));
-        HIPCHK(&c->err, c->csr_start.ensure((size_t)c->n + 2));
+        const size_t chunks = (size_t)pipeline_chunks(c);               // every chunk lane has its own row counters and scan scratch
+        HIPCHK(&c->err, c->csr_cnt.ensure(chunks * csr_stride((int)c->n)));
+        HIPCHK(&c->err, c->csr_start.ensure(chunks * ((size_t)c->n + 2)));
         HIPCHK(&c->err, c->grouped.ensure(surv_cap));
         size_t tmp_bytes = 0;
         HIPCHK(&c->err, rocprim::exclusive_scan(nullptr, tmp_bytes, c->csr_cnt.p, c->csr_start.p, 0, (size_t)c->n, rocprim::plus<int>(), c->stream));
-        HIPCHK(&c->err, c->scan_tmp.ensure(tmp_bytes + 256));
+        c->scan_tmp_stride = std::max(c->scan_tmp_stride, (tmp_bytes + 511) / 256 * 256);
+        HIPCHK(&c->err, c->scan_tmp.ensure(chunks * c->scan_tmp_stride));
     }
     if (!c->h_pc) HIPCHK(&c->err, hipHostMalloc((void**)&c->h_pc, sizeof(PassCounters) * (kMaxChunks + 1), hipHostMallocDefault));
     return SELHIP_OK;
@@ -1002,8 +1064,13 @@ int selhip_ctx_set_param(selhip_ctx* c, const char* name, int value) {
         c->join_bits = value;
         return SELHIP_OK;
     }
+    if (!std::strcmp(name, "group_label")) {
+        if (value < -1 || value > 1) { set_err(&c->err, "group_label must be -1 (automatic), 0 or 1"); return SELHIP_E_BADARG; }
+        c->group_label = value;
+        return SELHIP_OK;
+    }
     if (!std::strcmp(name, "hist_run")) {
-        if (value < 1 || value > 1024) { set_err(&c->err, "hist_run must be in [1, 1024]"); return SELHIP_E_BADARG; }
+        if (value < 0 || value > 1024) { set_err(&c->err, "hist_run must be in [0, 1024] (0 = automatic)"); return SELHIP_E_BADARG; }
         c->hist_run = value;
         return SELHIP_OK;
     }

@@ -122,9 +122,11 @@ const char* selhip_last_error(const selhip_ctx* ctx);
 
 /* Run all work of this context on `hip_stream` (a hipStream_t passed as void*; NULL = null stream). */
 int selhip_ctx_set_stream(selhip_ctx* ctx, void* hip_stream);
-/* Stage pipeline of a pass: the query rows are cut into `chunks` equal-pair chunks; stage 1 (all-pairs, VALU-bound)
- * of chunk c+1 runs on one internal stream while stage 2 (HLL union histograms, memory/LDS-bound) of chunk c runs on
- * another.  -1 / 0 / 1 = off (the default: measured slower or equal on MI355X), 2..8 = chunk count. */
+/* Chunk lanes of a pass (smh_a / hll_a+smh_a): the query rows are cut into `chunks` equal-pair chunks and every chunk runs its
+ * whole chain (join, verify, [auxiliary criterion], grouping, HLL union histograms, estimate) on one of two internal streams
+ * (the context's own and one more), so that one chunk's short tail kernels run beside the other chunk's join.
+ * -1 = automatic (the default: 2 chunks from 3e8 pairs per pass with the signature join, else 1), 0 / 1 = off, 2..8 = chunk
+ * count.  Results and counters do not depend on it.  (Round 1's stage-1-stream / stage-2-stream pipeline was replaced.) */
 int selhip_ctx_set_pipeline(selhip_ctx* ctx, int chunks);
 /* Row interleave for sharding a pass over several devices/ranks: the rows [row_begin, row_end) of the following runs are
  * cut into blocks of block_rows rows (a multiple of 32) and the run evaluates only the blocks b with b % n_parts == part.
@@ -146,7 +148,11 @@ int selhip_ctx_set_candidate_begin(selhip_ctx* ctx, int64_t k_min);
  *   "join_db"     1 (default) / 0: double-buffered query batches in the DPP form of the 16-bit join
  *   "join_wpb"    waves per block of the 16-bit join: LDS form 4 (default) or 8, DPP form 1 or 4
  *   "sig_tile"    1 (default): signature build 16 genomes per block with an LDS transpose; 0: one thread per bucket
- *   "hist_run"    pairs a wave of stage 2a takes at a time (default 1);  "hist_blocks"  its one-wave blocks (multiple of 8);
+ *   "hist_run"    pairs a wave of stage 2a takes at a time (0 = automatic: 1, or 4 with the label order);
+ *   "hist_blocks" its one-wave blocks (multiple of 8);
+ *   "group_label" stage-2 grouping lays the query-row buckets out by label = a row's smallest partner, so that the pairs of a
+ *                 cluster of similar genomes are neighbours in the list and their HLL rows stay in L2 (-1 = automatic: sets
+ *                 whose HLL rows exceed 192 MiB and passes of >= 4e8 pairs; 0 off; 1 on);
  *   "hist_pad"    extra LDS bytes per stage-2a block (lowers the resident waves per CU; measurement knob)
  *   "verify_fb"   test hook: 1 sends every candidate through the hash-collision fallback of the verification
  *   "init_cap"    test hook: initial capacity of the candidate / survivor / result lists (they grow and the pass repeats)

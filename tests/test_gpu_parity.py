@@ -165,16 +165,25 @@ def test_row_shards_union_equals_whole(oracle):
             assert len(whole) > 1000
 
 
-def test_pipelined_pass_equals_plain(oracle):
-    """stage 1 / stage 2 of row chunks on two internal streams (selhip_ctx_set_pipeline): same pairs, same counters"""
+def test_chunk_lanes_equal_plain(oracle):
+    """row chunks as whole chains on two internal streams (selhip_ctx_set_pipeline; automatic from 2e7 pairs per pass): same
+    pairs, same counters -- smh_a and the two-stage criterion, whole range / sub-range / interleaved parts"""
     cfg = make_golden.GOLDEN_SYNTH["synth_flat_n1000_m256"]
-    hll, aux, cards, _, _ = sorted_set(cfg, oracle)
+    hll, aux, cards, _, aux_hll = sorted_set(cfg, oracle)
     r, b = pkg.banding(cfg.m, cfg.tau)
     want, st = oracle.select(hll, aux, cards, cfg.tau, r, b)
     with Selector(0) as sel:
         sel.upload(hll, aux, cards)
+        sel.upload_aux_hll(aux_hll, 8)
+        sel.set_criterion(pkg.CRIT_HLL_A_SMH_A)
+        sel.set_pipeline(0)
+        want2 = sel.run(cfg.tau, MODE_CB_SMH, r, b)
+        st2 = sel.stats()
+        assert 0 < len(want2) <= len(want)
         for chunks in (0, 2, 3, 4, 8):
             sel.set_pipeline(chunks)
+            sel.set_param("group_label", chunks % 4 == 0)     # with and without the label order of the grouping
+            sel.set_criterion(pkg.CRIT_SMH_A)
             for algo in (ALGO_SIG, ALGO_STREAM):
                 for rows in (None, (100, 900)):
                     got = sel.run(cfg.tau, MODE_CB_SMH, r, b, algo=algo, rows=rows)
@@ -183,6 +192,17 @@ def test_pipelined_pass_equals_plain(oracle):
                     if rows is None:
                         s = sel.stats()
                         assert s["survivors"] == st["survivors"] and s["evaluated"] == st["evaluated"]
+            parts = []
+            for part in range(3):
+                sel.set_row_interleave(32, 3, part)
+                parts.append(sel.run(cfg.tau, MODE_CB_SMH, r, b))
+            sel.set_row_interleave(0, 1, 0)
+            cat = np.concatenate(parts)
+            assert_same_pairs(cat[np.lexsort((cat["k"], cat["i"]))], want)
+            sel.set_criterion(pkg.CRIT_HLL_A_SMH_A)
+            got = sel.run(cfg.tau, MODE_CB_SMH, r, b)
+            assert np.array_equal(got, want2)
+            assert sel.stats() == st2
 
 
 def test_interleaved_row_blocks_tile_the_pair_space(oracle):
@@ -276,16 +296,18 @@ def test_join_and_histogram_variants(oracle):
                 assert s["candidates"] == cand          # the 32-bit candidate set is the same whichever join produced it
             sel.set_param("join_bits", 16); sel.set_param("join_db", 1); sel.set_param("verify_fb", 0); sel.set_param("join_wpb", 4)
             sel.set_param("join_q", 1); sel.set_param("join_qt", 0)
-            for run, blocks in ((1, 8), (3, 64), (8, 2048), (1024, 16384), (1, 16384)):
-                sel.set_param("hist_run", run); sel.set_param("hist_blocks", blocks)
+            for run, blocks, label in ((1, 8, 0), (3, 64, 1), (8, 2048, 0), (1024, 16384, 1), (1, 16384, 0), (0, 16384, 1), (0, 16384, -1)):
+                sel.set_param("hist_run", run); sel.set_param("hist_blocks", blocks); sel.set_param("group_label", label)
                 assert_same_pairs(sel.run(tau, MODE_CB_SMH, r, b), want)
-            for bad in (("join_bits", 24), ("join_qt", 24), ("join_wpb", 2), ("init_cap", -1), ("hist_blocks", 12), ("hist_run", 0), ("no_such_param", 1)):
+                assert_same_pairs(sel.run(tau, MODE_CB_SMH, r, b, algo=ALGO_STREAM), want)      # rows tallied by csr_count_kernel
+            for bad in (("join_bits", 24), ("join_qt", 24), ("join_wpb", 2), ("init_cap", -1), ("hist_blocks", 12), ("hist_run", -1), ("group_label", 2),
+                        ("no_such_param", 1)):
                 with pytest.raises(pkg.SelhipError):
                     sel.set_param(*bad)
 
 
 @pytest.mark.parametrize("algo", [ALGO_SIG, ALGO_STREAM, ALGO_HASHJOIN])
-@pytest.mark.parametrize("grouping", [True, False])
+@pytest.mark.parametrize("grouping", ["label", True, False])
 def test_list_overflow_grows_and_repeats(oracle, algo, grouping):
     """the candidate / survivor / result lists start far too small ("init_cap" test hook): the pass must notice from its exact
     counters, grow the lists and repeat -- never read or write past a list (the per-row tally of verify16_kernel
@@ -297,7 +319,8 @@ def test_list_overflow_grows_and_repeats(oracle, algo, grouping):
     assert st["survivors"] > 600
     with Selector(0) as sel:
         sel.set_param("init_cap", 128)                       # 2 records per append segment of the join
-        sel.set_stage2_grouping(grouping)
+        sel.set_stage2_grouping(bool(grouping))
+        sel.set_param("group_label", 1 if grouping == "label" else 0)
         sel.upload(hll, aux, cards)
         got = sel.run(0.5, MODE_SMH, r, b, algo=algo)
         assert sel.last_attempts() >= 2
