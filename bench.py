@@ -44,6 +44,8 @@ sys.path.insert(0, str(ROOT))
 
 # ---- hardware constants (every one traceable to a file under profiles/ or to the guide) -----------------------------
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak (MI355X_MICROARCH.md, chip-level parameters)
+HBM_MEASURED_GBS = 6290.0      # same table: measured float4 copy (79 % of the spec)
+FABRIC_GATHER_GBS = 7400.0     # same guide, gather table: uniformly random whole rows of a 151 MB table (Infinity Cache) 7.4-7.9 TB/s
 N_SIMD = 256 * 4               # 256 CUs x 4 SIMDs
 SHADER_HZ = 2.4e9              # profiles/r02_valu_rate.txt: s_memtime tick rate 2407 MHz, rates quoted at 2400 MHz
 # profiles/r02_valu_rate.txt (scripts/microbench/valu_rate.hip), cycles per wave64 instruction per SIMD at >= 4 waves/SIMD:
@@ -69,7 +71,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip stream_kernel / harder_workload (profiling runs)")
     ap.add_argument("--no-grouping", action="store_true", help="stage 2 without bucketing the survivors by query row")
-    ap.add_argument("--pipeline", type=int, default=-1, help="-1 auto (2 chunk lanes from 3e8 pairs per pass), 0 off, 2..8 row chunks, each a whole chain on one of two streams")
+    ap.add_argument("--pipeline", type=int, default=-1, help="-1 auto (2 chunk lanes from 1e9 pairs per pass), 0 off, 2..8 row chunks, each a whole chain on one of two streams")
     ap.add_argument("--pcie", action="store_true", help="also time a PCIe-inclusive pass (host buffers -> upload -> run)")
     ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed and run the collectives even with one rank (RCCL smoke test)")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
@@ -266,6 +268,7 @@ def main():
     dom_key = "join" if used_sig else "stage1"
     dom_pass_ms = sel.kernel_ms(dom_key)                         # all launches of one pass (a pipelined pass: one per row chunk)
     dom_launches = max(1.0, sel.kernel_launches(dom_key))
+    dom_span_ms = sel.kernel_ms("join_span") if used_sig else -1.0   # first start -> last end of the pass's join launches (chunk lanes overlap them)
     sel.timing(1)                                                # outside the timed region: every kernel scope, a few passes
     for _ in range(5):
         step()
@@ -353,6 +356,14 @@ def main():
                 "bound": "valu_issue", "kernel": dom_name + " (stage 1, all-pairs)", "achieved": achieved / 1e9, "peak": peak / 1e9,
                 "unit": "G wave-instr/s", "frac": achieved / peak, "traffic": traffic, "traffic_source": traffic_src,
                 "avg_launch_ms": dom_ms, "launches_per_step": launches,
+                **({"concurrent_launches": {
+                    "span_ms": dom_span_ms, "frac_of_chip_while_running": row_waves * n_instr / (dom_span_ms * 1e-3) / peak,
+                    "note": "this pass is cut into row chunks whose chains run on two streams (selhip_ctx_set_pipeline, automatic from 1e9 pairs): "
+                            "the join launches run side by side, each on about half of the chip, so `frac` (work of a launch / its own duration / "
+                            "whole-chip peak, the same durations rocprofv3 reports) is about half of what the chip delivers while they run; "
+                            "span_ms = first start to last end of the pass's join launches, frac_of_chip_while_running = all their work / span / peak "
+                            "(the other chunk's verification / stage-2 kernels run inside that span too).  --pipeline 0 gives the single-launch figure"}}
+                   if launches > 1.5 and dom_span_ms > 0 else {}),
                 "instr_per_row_wave": mdl, "cycles_per_instr_at_peak": cyc_mix,
                 "peak_derivation": f"{N_SIMD} SIMDs x {SHADER_HZ / 1e9} GHz / mix-weighted issue cost; profiles/r02_valu_rate.txt: "
                                    f"VGPR-only VOP2 {CYC_VALU_PLAIN} cycles (two waves co-issue), every DPP/SDWA/SGPR-operand/VOP3/packed instruction "
@@ -370,14 +381,34 @@ def main():
                                           "both stage-1 kernels reuse every byte they load against a tile of queries, so the ratio exceeds 1; "
                                           "measured HBM traffic per launch is `roofline.traffic`"}
         if hist_ms > 0:
+            # stage 2a has two candidate bounds: the LDS (one ds_add_u32 per 64 register pairs) and the fabric behind L2 (HLL rows that are
+            # no longer in the XCD's 4 MiB L2 when their next pair comes up); both fractions are reported, the larger one binds
             ds_rate = surv0 * 256 / (hist_ms * 1e-3)
             ds_peak = 256 * SHADER_HZ / CYC_DS_2DWORD
-            out["stage2_roofline"] = {"bound": "lds_issue", "kernel": "hll_union_hist_runs_kernel", "achieved": ds_rate / 1e9, "peak": ds_peak / 1e9,
-                                      "unit": "G ds_add_u32 wave-instr/s", "frac": ds_rate / ds_peak, "ms_per_step": hist_ms,
+            fetch, fetch_src = None, None
+            t2 = ROOT / "profiles" / "stage2_traffic.json"
+            if t2.exists():
+                try:
+                    tj = json.loads(t2.read_text())
+                    per_launch = tj.get(args.workload + ("hard" if args.hard else ""))
+                    if per_launch:
+                        fetch = per_launch * max(1.0, sel.kernel_launches("hist"))
+                        fetch_src = tj.get("source", "") + " -- an earlier rocprofv3 --pmc run of this command, NOT measured by this run"
+                except Exception:
+                    fetch = None
+            fabric_peak = FABRIC_GATHER_GBS if n_genomes * 16384 <= (256 << 20) else HBM_MEASURED_GBS
+            out["stage2_roofline"] = {"kernel": "hll_union_hist_runs_kernel", "ms_per_step": hist_ms,
+                                      "lds_issue": {"achieved": ds_rate / 1e9, "peak": ds_peak / 1e9, "unit": "G ds_add_u32 wave-instr/s", "frac": ds_rate / ds_peak,
+                                                    "note": "one conflict-free ds_add_u32 per 64 register pairs, 256 per pair of the final list; peak = 256 CUs x one DS op of "
+                                                            f"2 dwords per {CYC_DS_2DWORD} cycles (MI355X_MICROARCH.md LDS table; profiles/r02_lds_rate.txt measures 4.4-5.1)"},
+                                      "beyond_l2_fetch": {"bytes_per_step": fetch, "achieved_GBs": (fetch / (hist_ms * 1e-3) / 1e9) if fetch else None,
+                                                          "peak_GBs": fabric_peak, "frac": (fetch / (hist_ms * 1e-3) / 1e9 / fabric_peak) if fetch else None,
+                                                          "source": fetch_src,
+                                                          "note": "peak = what MI355X_MICROARCH.md measures for gathered whole rows: 7 400 GB/s from the Infinity Cache "
+                                                                  "(tables up to ~150 MB), 6 000-6 300 GB/s from HBM; minimum traffic = every HLL row once"},
                                       "row_bytes_per_s": surv0 * 32768 / (hist_ms * 1e-3),
-                                      "note": "one conflict-free ds_add_u32 per 64 register pairs, 256 per surviving pair; peak = 256 CUs x one DS op of 2 dwords "
-                                              f"per {CYC_DS_2DWORD} cycles (MI355X_MICROARCH.md LDS table; profiles/r02_lds_rate.txt measures 4.4-5.1); "
-                                              "row_bytes_per_s = the 2 x 16 KiB of HLL registers per pair, served mostly by L2/MALL"}
+                                      "grouping": "automatic: label order (a row's smallest partner first) when the HLL rows exceed 192 MiB and the pass has "
+                                                  ">= 4e8 pairs, else query-row order"}
         if n_degenerate:
             out["config"]["degenerate_genomes"] = n_degenerate
 

@@ -88,12 +88,14 @@ struct DevBuf {
 
 struct KernelTimer {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
+    std::vector<long> ev_pass;          // the pass each pair was recorded in
     double total_ms = 0;
+    double span_ms = 0;                 // per pass: first start -> last end (chunk lanes run a kernel's launches side by side)
     long launches = 0;
 };
 
 constexpr int kMaxChunks = 8;
-constexpr double kAutoChunkPairs = 3e8;  // pairs per pass from which the automatic setting splits a pass into two chunk lanes
+constexpr double kAutoChunkPairs = 1e9;  // pairs per pass from which the automatic setting splits a pass into two chunk lanes
 static_assert(kCounterBlocks == kMaxChunks + 1, "common.cuh: counter blocks per pass");
 constexpr long long kEnumPairs = 1ll << 26;    // hll_a / hll_an as first criterion: pairs listed per sub-pass (512 MiB of int2)
 
@@ -212,6 +214,7 @@ struct TimerScope {
         if (on) {
             (void)hipEventRecord(b, st);
             c->timers[id].ev.emplace_back(a, b);
+            c->timers[id].ev_pass.push_back(c->timed_passes);
         }
     }
 };
@@ -231,16 +234,23 @@ struct StageIO {
 
 void drain_timers(selhip_ctx* c) {
     for (int t = 0; t < T_COUNT; ++t) {
-        for (auto& pr : c->timers[t].ev) {
-            float ms = 0;
-            if (hipEventSynchronize(pr.second) == hipSuccess && hipEventElapsedTime(&ms, pr.first, pr.second) == hipSuccess) {
-                c->timers[t].total_ms += ms;
-                c->timers[t].launches += 1;
+        KernelTimer& kt = c->timers[t];
+        for (size_t j = 0; j < kt.ev.size();) {
+            // the launches of one pass: sum of their durations, and the span they cover together
+            size_t e = j;
+            float lo = 0, hi = 0;
+            for (; e < kt.ev.size() && kt.ev_pass[e] == kt.ev_pass[j]; ++e) {
+                float ms = 0, a_off = 0, b_off = 0;
+                if (hipEventSynchronize(kt.ev[e].second) != hipSuccess) continue;
+                if (hipEventElapsedTime(&ms, kt.ev[e].first, kt.ev[e].second) == hipSuccess) { kt.total_ms += ms; kt.launches += 1; }
+                if (hipEventElapsedTime(&a_off, kt.ev[j].first, kt.ev[e].first) == hipSuccess &&
+                    hipEventElapsedTime(&b_off, kt.ev[j].first, kt.ev[e].second) == hipSuccess) { lo = std::min(lo, a_off); hi = std::max(hi, b_off); }
             }
-            (void)hipEventDestroy(pr.first);
-            (void)hipEventDestroy(pr.second);
+            kt.span_ms += hi - lo;
+            j = e;
         }
-        c->timers[t].ev.clear();
+        for (auto& pr : kt.ev) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
+        kt.ev.clear(); kt.ev_pass.clear();
     }
 }
 
@@ -1383,7 +1393,7 @@ int selhip_ctx_timing(selhip_ctx* c, int enable) {
     if (!c) return SELHIP_E_BADARG;
     (void)hipStreamSynchronize(c->stream);
     drain_timers(c);
-    for (int t = 0; t < T_COUNT; ++t) { c->timers[t].total_ms = 0; c->timers[t].launches = 0; }
+    for (int t = 0; t < T_COUNT; ++t) { c->timers[t].total_ms = 0; c->timers[t].launches = 0; c->timers[t].span_ms = 0; }
     c->timing = enable == 2 ? 2 : (enable != 0 ? 1 : 0);
     c->timed_passes = 0;
     return SELHIP_OK;
@@ -1396,6 +1406,8 @@ double selhip_ctx_kernel_ms(const selhip_ctx* c, const char* name) {
     for (int t = 0; t < T_COUNT; ++t)
         if (!std::strcmp(name, kTimerNames[t]))
             return (c->timers[t].launches && passes) ? c->timers[t].total_ms / (double)passes : -1.0;
+    if (!std::strcmp(name, "join_span"))
+        return (c->timers[T_JOIN].launches && passes) ? c->timers[T_JOIN].span_ms / (double)passes : -1.0;
     return -1.0;
 }
 

@@ -125,7 +125,7 @@ int selhip_ctx_set_stream(selhip_ctx* ctx, void* hip_stream);
 /* Chunk lanes of a pass (smh_a / hll_a+smh_a): the query rows are cut into `chunks` equal-pair chunks and every chunk runs its
  * whole chain (join, verify, [auxiliary criterion], grouping, HLL union histograms, estimate) on one of two internal streams
  * (the context's own and one more), so that one chunk's short tail kernels run beside the other chunk's join.
- * -1 = automatic (the default: 2 chunks from 3e8 pairs per pass with the signature join, else 1), 0 / 1 = off, 2..8 = chunk
+ * -1 = automatic (the default: 2 chunks from 1e9 pairs per pass with the signature join, else 1), 0 / 1 = off, 2..8 = chunk
  * count.  Results and counters do not depend on it.  (Round 1's stage-1-stream / stage-2-stream pipeline was replaced.) */
 int selhip_ctx_set_pipeline(selhip_ctx* ctx, int chunks);
 /* Row interleave for sharding a pass over several devices/ranks: the rows [row_begin, row_end) of the following runs are
@@ -228,7 +228,8 @@ int selhip_ctx_last_attempts(const selhip_ctx* ctx);
 
 /* device time (ms, HIP events on the stream each kernel is launched on) of the named kernel PER PASS, averaged over
  * the passes since the last reset (a pipelined pass launches a kernel once per row chunk: the figure is their sum);
- * names: "prep", "sigbuild", "join", "verify", "stage1", "aux", "group", "hist", "select", "total".  <0 if never launched.
+ * names: "prep", "sigbuild", "join", "verify", "stage1", "aux", "group", "hist", "select", "total"; "join_span" = first start to
+ * last end of the pass's join launches (chunk lanes run them side by side).  <0 if never launched.
  * selhip_ctx_kernel_launches: launches of that kernel per pass. */
 double selhip_ctx_kernel_ms(const selhip_ctx* ctx, const char* name);
 double selhip_ctx_kernel_launches(const selhip_ctx* ctx, const char* name);

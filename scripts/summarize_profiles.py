@@ -89,6 +89,14 @@ if dom:
     t[key] = traffic
     t["source"] = "profiles/*_pmc_summary.json"
     tfile.write_text(json.dumps(t, indent=1))
+h = [v for k, v in summary["kernels"].items() if "hll_union_hist_runs" in k]
+if h and "hbm_read_bytes_per_launch" in h[0]:
+    # stage 2a: bytes fetched from beyond L2 per launch (average over the launches of the run, empty windows included)
+    tfile = out / "stage2_traffic.json"
+    t = json.loads(tfile.read_text()) if tfile.exists() else {}
+    t[key.split(":")[0]] = h[0]["hbm_read_bytes_per_launch"]
+    t["source"] = "profiles/*_pmc_summary.json (FETCH_SIZE of hll_union_hist_runs_kernel, calibrated)"
+    tfile.write_text(json.dumps(t, indent=1))
 (out / f"{tag}_pmc_summary.json").write_text(json.dumps(summary, indent=1))
 print(json.dumps(summary.get("stage1")), summary.get("fetch_calibration"))
 for k, e in summary["kernels"].items():

@@ -166,7 +166,7 @@ def test_row_shards_union_equals_whole(oracle):
 
 
 def test_chunk_lanes_equal_plain(oracle):
-    """row chunks as whole chains on two internal streams (selhip_ctx_set_pipeline; automatic from 2e7 pairs per pass): same
+    """row chunks as whole chains on two internal streams (selhip_ctx_set_pipeline; automatic from 1e9 pairs per pass): same
     pairs, same counters -- smh_a and the two-stage criterion, whole range / sub-range / interleaved parts"""
     cfg = make_golden.GOLDEN_SYNTH["synth_flat_n1000_m256"]
     hll, aux, cards, _, aux_hll = sorted_set(cfg, oracle)
