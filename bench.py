@@ -390,9 +390,8 @@ def main():
             if t2.exists():
                 try:
                     tj = json.loads(t2.read_text())
-                    per_launch = tj.get(args.workload + ("hard" if args.hard else ""))
-                    if per_launch:
-                        fetch = per_launch * max(1.0, sel.kernel_launches("hist"))
+                    fetch = tj.get(args.workload + ("hard" if args.hard else ""))      # bytes per pass
+                    if fetch:
                         fetch_src = tj.get("source", "") + " -- an earlier rocprofv3 --pmc run of this command, NOT measured by this run"
                 except Exception:
                     fetch = None

@@ -77,9 +77,10 @@ __device__ __forceinline__ void zero_next_counters(int t, int n_threads, PassCou
 __global__ void cb_bounds_kernel(const double* __restrict__ cards, int n, double tau, int use_cb,
                                  RowMap rm, u64* __restrict__ ecard, int* __restrict__ hi,
                                  PassCounters* __restrict__ pc, int* __restrict__ csr_zero, int csr_zero_n, int cand_begin,
-                                 PassCounters* __restrict__ zero_pc) {
+                                 PassCounters* __restrict__ zero_pc, u64* __restrict__ seg_zero, int seg_zero_n) {
     const int t = (int)(blockIdx.x * blockDim.x + threadIdx.x);
     zero_next_counters(t, (int)(gridDim.x * blockDim.x), zero_pc, kCounterBlocks);
+    for (int j = t; j < seg_zero_n; j += (int)(gridDim.x * blockDim.x)) seg_zero[j] = 0;      // the join's append-segment counters
     // stage 2's per-row counters (count / fill cursors, one set per chunk lane) for this pass
     for (int j = t; j < csr_zero_n; j += (int)(gridDim.x * blockDim.x)) csr_zero[j] = 0;
     cb_bounds_body(t, cards, n, tau, use_cb, rm, ecard, hi, pc, cand_begin);

@@ -133,13 +133,23 @@ void csr_count_kernel(const selhip_int2_t* __restrict__ pairs, const u64* __rest
 // row i is paired with (itself if none is smaller) -- for a clique of similar genomes that is the clique's first member, so
 // the clique's buckets become neighbours and stage 2a's waves, which walk the list in order XCD by XCD, meet each of its
 // rows while it is still in L2.  Any other pair graph only gets a different (still valid) order: results do not depend on it.
-//   lab[k] = max over pairs (i, k) of n - i   (0 = no smaller partner; tallied where the pairs are counted)
+//   lab[k] = max over pairs (i, k) of n - i   (0 = no smaller partner; tallied where the pairs are counted);
+//   label(i) = the root of i's smallest-partner chain (at most 8 hops)
 //   csr_label_sum:    gsum[label(i)] += cnt[i]
 //   (exclusive scan of gsum -> gbase, rocPRIM)
 //   csr_label_assign: start[i] = atomicAdd(&gbase[label(i)], cnt[i])     (order of the rows inside a label group: free)
 __device__ __forceinline__ int csr_label_of(const int* __restrict__ lab, int i, int n) {
-    const int v = lab[i];
-    return v ? n - v : i;
+    // follow the smallest-partner links to their root (a row with no smaller partner): in a cluster that is not a full clique --
+    // e.g. after the auxiliary criterion removed a third of its pairs -- a member's smallest partner need not be the cluster's
+    // first member, and one hop would split the cluster into several label groups far apart in the list
+    int cur = i;
+#pragma unroll 1
+    for (int hop = 0; hop < 8; ++hop) {
+        const int v = lab[cur];
+        if (!v) break;
+        cur = n - v;                      // strictly smaller rank: the walk ends
+    }
+    return cur;
 }
 
 __global__ __launch_bounds__(kBlock)
@@ -171,6 +181,9 @@ void csr_fill_kernel(const selhip_int2_t* __restrict__ pairs, const u64* __restr
     }
 }
 
+// (The three steps as ONE single-block launch with the group sums in LDS, for N <= 32 768, were built and measured at cfg3: grouping
+// 9.5 -> 20 us (five dependent memory round trips on one CU), stage 2a 114 -> 106 us, step 0.311 -> 0.313 ms -- dropped; sets that fit
+// the Infinity Cache keep the query-row order.)
 constexpr int kSmallScanMax = 32768;        // rows whose counts one block scans in LDS (128 KiB); larger N: rocPRIM scan + csr_fill_kernel
 
 // csr_scan_fill_kernel: the two grouping steps in ONE launch for n <= kSmallScanMax: every block repeats the exclusive scan of
@@ -261,6 +274,8 @@ void hll_union_hist_runs_kernel(const uint8_t* __restrict__ hll, const selhip_in
 #pragma unroll
     for (int t = 0; t < 16; ++t) row4[(t + lane) & 15] = make_uint4(0u, 0u, 0u, 0u);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    // (handing the tasks of an XCD's eighth out through a queue counter instead of this static stride -- so that the resident waves
+    // always work on neighbouring tasks -- was measured: cfg4 475-478 vs 480 us, cfg5 927-942 vs 934 us, cfg3 slower; dropped)
     for (u64 task = t_begin + (blockIdx.x >> 3); task < t_end; task += per_xcd) {
     const u64 j0 = task * run_len, j1 = min(j0 + run_len, n_pairs);
     selhip_int2_t pr = pairs[j0];

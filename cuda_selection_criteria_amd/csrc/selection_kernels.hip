@@ -95,6 +95,7 @@ struct KernelTimer {
 };
 
 constexpr int kMaxChunks = 8;
+constexpr size_t kSegCounterSlots = (size_t)(kMaxChunks + 1) * kAppendSegs * kSegStride;    // the join's append-segment counters (u64 slots)
 constexpr double kAutoChunkPairs = 1e9;  // pairs per pass from which the automatic setting splits a pass into two chunk lanes
 static_assert(kCounterBlocks == kMaxChunks + 1, "common.cuh: counter blocks per pass");
 constexpr long long kEnumPairs = 1ll << 26;    // hll_a / hll_an as first criterion: pairs listed per sub-pass (512 MiB of int2)
@@ -646,12 +647,12 @@ constexpr size_t kLabelOrderBytes = (size_t)192 << 20;     // HLL rows beyond th
 bool label_order(const selhip_ctx* c) {
     if (!(c->p == 14 && c->group_stage2)) return false;
     if (c->group_label >= 0) return c->group_label == 1;
-    // its three extra launches (~15 us) only pay on a pass with enough pairs in stage 2; the pair space is the proxy known here
-    // (one of 8 ranks of cfg4, 1.6e8 pairs: 0.515 -> 0.529 ms with it; one of 8 ranks of cfg5, 6.2e8: 1.613 -> 1.577 ms)
+    // its three extra launches (~15 us) only pay where stage 2a is bound by fetches from beyond L2 AND has enough pairs: HLL rows
+    // beyond the Infinity Cache and -- the proxy known here -- a large pair space (one of 8 ranks of cfg4, 1.6e8 pairs: 0.515 -> 0.529 ms
+    // with it; one of 8 ranks of cfg5, 6.2e8: 1.613 -> 1.577 ms; cfg3, whose rows fit the Infinity Cache: 0.311 -> 0.313 ms)
     return (size_t)c->n * 16384 > kLabelOrderBytes && (double)pair_bound(c->n, c->row_begin, c->row_end) / std::max(1, c->il_parts) >= kLabelOrderPairs;
 }
 
-// final criterion over a list of pairs: HLL-14 union estimate + Jaccard (selection.cpp:286-288), windows of the counts buffer
 int enqueue_tail(selhip_ctx* c, const Chain& ch, const selhip_int2_t* final_list, const u64* final_count, u64 final_cap,
                  bool counted, double tau, PassCounters* pc0) {
     const int n = (int)c->n;
@@ -780,7 +781,8 @@ int enqueue_pass(selhip_ctx* c) {
         TimerScope t(c, T_PREP);
         hipLaunchKernelGGL(cb_bounds_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream,
                            c->d_cards, n, tau, c->mode == SELHIP_MODE_CB_SMH ? 1 : 0, row_map(c, rb, re), c->ecard.p, c->hi.p, pc0,
-                           (c->p == 14 && c->group_stage2) ? c->csr_cnt.p : nullptr, (c->p == 14 && c->group_stage2) ? (int)c->csr_cnt.cap : 0, (int)c->cand_begin, pc_next);
+                           (c->p == 14 && c->group_stage2) ? c->csr_cnt.p : nullptr, (c->p == 14 && c->group_stage2) ? (int)c->csr_cnt.cap : 0, (int)c->cand_begin, pc_next,
+                           c->seg_cnt.p, (int)c->seg_cnt.cap);
         HIPCHK(&c->err, hipGetLastError());
         if (smh_crit && stream_supported(c->m, c->n_rows)) {
             // ALGO_STREAM: the bucket-interleaved copy of the sketches (lane l = buckets [l*B, (l+1)*B)), rebuilt every pass
@@ -899,7 +901,7 @@ int ensure_scratch(selhip_ctx* c, size_t surv_cap, size_t res_cap) {
         HIPCHK(&c->err, hipMemsetAsync(c->pc.p, 0, sizeof(PassCounters) * 2 * (kMaxChunks + 1), c->stream));
         c->pc_flip = 0;
     }
-    HIPCHK(&c->err, c->seg_cnt.ensure((size_t)(kMaxChunks + 1) * kAppendSegs * kSegStride));
+    HIPCHK(&c->err, c->seg_cnt.ensure(kSegCounterSlots));
     if (!c->st_stage1) {
         HIPCHK(&c->err, hipStreamCreateWithFlags(&c->st_stage1, hipStreamNonBlocking));
         HIPCHK(&c->err, hipStreamCreateWithFlags(&c->st_stage2, hipStreamNonBlocking));

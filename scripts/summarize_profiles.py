@@ -89,14 +89,18 @@ if dom:
     t[key] = traffic
     t["source"] = "profiles/*_pmc_summary.json"
     tfile.write_text(json.dumps(t, indent=1))
-h = [v for k, v in summary["kernels"].items() if "hll_union_hist_runs" in k]
-if h and "hbm_read_bytes_per_launch" in h[0]:
-    # stage 2a: bytes fetched from beyond L2 per launch (average over the launches of the run, empty windows included)
+hk = [k for k in fetch if "hll_union_hist_runs" in k]
+sk = [k for k in fetch if "sig_build_kernel" in k or "cb_bounds_kernel" in k]       # one launch per pass
+if hk and sk:
+    # stage 2a: bytes fetched from beyond L2 per PASS (all windows and chunk lanes of a pass together)
+    passes = sum(len(fetch[k]["FETCH_SIZE"]) for k in sk)
+    per_pass = sum(sum(fetch[k]["FETCH_SIZE"]) for k in hk) * 1024 * fix / passes
     tfile = out / "stage2_traffic.json"
     t = json.loads(tfile.read_text()) if tfile.exists() else {}
-    t[key.split(":")[0]] = h[0]["hbm_read_bytes_per_launch"]
-    t["source"] = "profiles/*_pmc_summary.json (FETCH_SIZE of hll_union_hist_runs_kernel, calibrated)"
+    t[key.split(":")[0]] = per_pass
+    t["source"] = "profiles/*_pmc_summary.json (FETCH_SIZE of hll_union_hist_runs_kernel, calibrated; bytes per pass)"
     tfile.write_text(json.dumps(t, indent=1))
+    summary["stage2"] = {"kernel": "hll_union_hist_runs_kernel", "beyond_l2_bytes_per_pass": per_pass}
 (out / f"{tag}_pmc_summary.json").write_text(json.dumps(summary, indent=1))
 print(json.dumps(summary.get("stage1")), summary.get("fetch_calibration"))
 for k, e in summary["kernels"].items():

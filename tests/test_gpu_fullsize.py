@@ -41,9 +41,10 @@ def test_baseline_configs_bit_exact_vs_oracle(oracle, key):
 
 
 def test_grouping_scan_in_lds_above_64k(oracle):
-    """17 000 genomes: the survivors' per-row counts are scanned in every block's LDS by csr_scan_fill_kernel with a 68 KB dynamic
-    allocation (above the 64 KB default limit, below the 32 768-row switch to the rocPRIM scan) -- the sizes the weak-scaling bench
-    reaches at 4 and 8 GPUs (20 000 / 28 280 genomes); bit-exact against the oracle"""
+    """17 000 genomes: the grouping's single-block kernels work on n ints of LDS with a 68 KB dynamic allocation (above the 64 KB
+    default limit, below the 32 768-row switch to the rocPRIM scan) -- the sizes the weak-scaling bench reaches at 4 and 8 GPUs
+    (20 000 / 28 280 genomes): the query-row order (csr_scan_fill_kernel, every block repeating the scan; the automatic choice here)
+    and the label order (forced: group sums, rocPRIM scan, bucket starts, scatter); bit-exact against the oracle"""
     from cuda_selection_criteria_amd.synth import SynthConfig
     cfg = SynthConfig("n17000", 17_000, 128, 0.9, 0x5EED0044)
     hll_t, aux_t, cards_t, _, _ = pkg.synth_device(cfg)
@@ -52,10 +53,12 @@ def test_grouping_scan_in_lds_above_64k(oracle):
     want, st = oracle.select(hll, aux, cards, cfg.tau, r, b, use_cb=False, threads=16)
     with Selector(0) as sel:
         sel.attach(hll_t, aux_t, cards_t)
-        got = sel.run(cfg.tau, MODE_SMH, r, b)
-        assert same(got, want) and len(got) > 10_000
-        s = sel.stats()
-        assert s["evaluated"] == st["evaluated"] and s["survivors"] == st["survivors"]
+        for label in (-1, 0, 1):
+            sel.set_param("group_label", label)
+            got = sel.run(cfg.tau, MODE_SMH, r, b)
+            assert same(got, want) and len(got) > 10_000
+            s = sel.stats()
+            assert s["evaluated"] == st["evaluated"] and s["survivors"] == st["survivors"]
 
 
 def test_config4_scale_properties():

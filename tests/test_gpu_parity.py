@@ -203,6 +203,16 @@ def test_chunk_lanes_equal_plain(oracle):
             got = sel.run(cfg.tau, MODE_CB_SMH, r, b)
             assert np.array_equal(got, want2)
             assert sel.stats() == st2
+        # timers: a kernel's figure is the sum over its launches of a pass, "join_span" the time from the first start to the last end
+        sel.set_pipeline(2)
+        sel.set_criterion(pkg.CRIT_SMH_A)
+        sel.timing(1)
+        for _ in range(3):
+            sel.run(cfg.tau, MODE_CB_SMH, r, b, algo=ALGO_SIG)
+        assert sel.kernel_launches("join") == 2.0 and sel.kernel_launches("hist") == 2.0
+        assert 0 < sel.kernel_ms("join_span") <= sel.kernel_ms("total")
+        assert sel.kernel_ms("join_span") < sel.kernel_ms("join") * 1.5 + 0.05
+        sel.timing(0)
 
 
 def test_interleaved_row_blocks_tile_the_pair_space(oracle):
