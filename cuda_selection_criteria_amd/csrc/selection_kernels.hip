@@ -167,7 +167,7 @@ struct selhip_ctx {
     long long enum_pairs = kEnumPairs;  // hll_a / hll_an as first criterion: pairs listed per sub-pass (test hook "enum_pairs")
     int sig_tile = 1;                   // signature build: tiled form (0 = one thread per bucket, the round-1 kernel)
     int init_cap = 0;                   // test hook: initial capacity of the survivor / candidate lists (0 = sized from the workload)
-    int join_qt = 0;                    // query rows per signature-join block (multiple of 16); 0 = automatic: 64 rows up to 4.5e8 pairs per pass
+    int join_qt = 0;                    // query rows per signature-join block (multiple of 16); 0 = automatic: 32 rows below 1e8 pairs per pass, 64 up to 4.5e8
                                         // (30 000 genomes on one GPU), 128 beyond.  With the segmented appends: cfg3 112 / 114 / 127 us at 64 / 96 / 128 rows (finer tiles balance
                                         // the 1 024 SIMDs better), cfg4 2.12 / 2.10 / 2.07 ms (a block's prologue -- 32 candidate loads per lane,
                                         // tile staging -- is amortised over more rows), cfg5 8.31 / 8.16 / 8.20 ms
@@ -334,7 +334,8 @@ unsigned grid_for(u64 items, unsigned per_block, unsigned max_blocks);
 // tile height of the signature joins: the configured one, or the automatic choice (see selhip_ctx::join_qt)
 int join_tile_rows(const selhip_ctx* c) {
     const double pairs_here = 0.5 * (double)c->n * (double)c->n / std::max(1, c->il_parts);       // this context's share of the triangle
-    int qt = c->join_qt > 0 ? c->join_qt : (pairs_here >= 4.5e8 ? 128 : 64);
+    // (< 1e8 pairs: 32-row tiles -- twice the work units for the 8 192 wave slots, a shorter tail: cfg3's join 108.5 -> 104.3 us)
+    int qt = c->join_qt > 0 ? c->join_qt : (pairs_here >= 4.5e8 ? 128 : pairs_here >= 1e8 ? 64 : 32);
     if (c->il_parts > 1) { qt = std::min(qt, c->il_block); while (c->il_block % qt) qt -= 16; }
     return qt;
 }

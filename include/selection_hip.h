@@ -140,7 +140,7 @@ int selhip_ctx_set_candidate_begin(selhip_ctx* ctx, int64_t k_min);
 /* Tunables (integers by name; results never depend on them):
  *   "join_q"      query side of the 16-bit signature join: 1 (default) = tile of query rows staged in LDS, broadcast LDS reads
  *                 (sigl_join_kernel); 0 = DPP row broadcast from registers (sig16_join_kernel, the round-1 form)
- *   "join_qt"     query rows per block of the signature join: 0 (default) = automatic (64 below 4.5e8 pairs per pass, 128
+ *   "join_qt"     query rows per block of the signature join: 0 (default) = automatic (32 below 1e8 pairs per pass, 64 below 4.5e8, 128
  *                 beyond), or a multiple of 16
  *   "join_bits"   16 (default): all-pairs join on 16-bit band signatures packed two per dword, its matches cut back to the
  *                 32-bit candidate set during verification; 15: the same with 15-bit signatures and flag arithmetic made of
