@@ -824,7 +824,10 @@ int enqueue_pass(selhip_ctx* c) {
         // the signature build done twice.
         long long bnd[kMaxChunks + 1];
         chunk_rows(n, rb, re, chunks, c->il_parts > 1 ? (long long)c->il_block * c->il_parts : 1, bnd);
-        // lane 0 is the context's own stream (cross-stream waits cost ~10 us each: one to start lane 1, one to join it)
+        // lane 0 is the context's own stream (cross-stream waits cost ~10 us each: one to start lane 1, one to join it).
+        // (Staggering the lanes -- chunk k's join waits for chunk k-1's join, so that every tail runs beside the NEXT join and only the
+        // last tail is exposed -- was measured: cfg4 2.78 vs 2.73 ms, cfg5 9.79 vs 9.74 ms with 2 chunks, no better with 4: the tail
+        // kernels take from the join what they use, the chip is not idle in either phase.  profiles/r02_chunk_lanes.txt)
         hipStream_t lane[2] = {c->stream, c->st_stage1};
         HIPCHK(&c->err, hipEventRecord(c->ev_start, c->stream));
         HIPCHK(&c->err, hipStreamWaitEvent(lane[1], c->ev_start, 0));
@@ -945,8 +948,9 @@ int ensure_scratch(selhip_ctx* c, size_t surv_cap, size_t res_cap) {
             HIPCHK(&c->err, c->hj_tmp.ensure(tmp_bytes + 256));
         }
     }
-    // histogram scratch: 256 B per pair, at most 1 Mi pairs per window (256 MiB)
-    HIPCHK(&c->err, c->counts.ensure(std::min<size_t>(std::max(c->surv.cap, (size_t)c->n), (size_t)1 << 20) * 64));
+    // histogram scratch: 256 B per pair, at most 4 Mi pairs per window (1 GiB of 288; the lists are sized for the join's 16-bit
+    // matches, several times the final list, so a smaller window only adds empty histogram + estimate launches: 6 -> 2 per chain at cfg5)
+    HIPCHK(&c->err, c->counts.ensure(std::min<size_t>(std::max(c->surv.cap, (size_t)c->n), (size_t)1 << 22) * 64));
     HIPCHK(&c->err, c->results.ensure(res_cap));
     if (c->group_stage2 && c->p == 14) {
         const size_t chunks = (size_t)pipeline_chunks(c);               // every chunk lane has its own row counters and scan scratch
