@@ -168,7 +168,7 @@ def hip_lib():
 def host_lib():
     global _host
     if _host is None:
-        path = LIB_DIR / "libselhost.so"
+        path = Path(os.environ.get("SELHOST_LIB", LIB_DIR / "libselhost.so"))    # SELHOST_LIB: e.g. a sanitizer build (scripts/asan_host.sh)
         if not path.exists():
             raise ImportError(f"{path} is missing: build it with `make -C {_PKG / 'csrc'}`")
         _host = _bind(C.CDLL(str(path)), HOST_SYMBOLS)

@@ -3,6 +3,7 @@
 Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg import this module.
 """
 import ctypes as C
+import os
 from pathlib import Path
 
 import numpy as np
@@ -13,7 +14,7 @@ ORC_PAIR = np.dtype([("i", "<i4"), ("k", "<i4"), ("jacc", "<f8")], align=True)
 
 class Oracle:
     def __init__(self):
-        self.lib = C.CDLL(str(ROOT / "oracle" / "liboracle.so"))
+        self.lib = C.CDLL(os.environ.get("ORACLE_LIB", str(ROOT / "oracle" / "liboracle.so")))   # ORACLE_LIB: a sanitizer build (scripts/asan_host.sh)
         L = self.lib
         L.orc_ertl_ml_estimate_ex.restype = C.c_double
         L.orc_ertl_ml_estimate_ex.argtypes = [C.c_void_p, C.c_uint, C.c_uint, C.c_double, C.c_int]
@@ -109,7 +110,7 @@ class BuildOracle:
     """oracle/build_sketch_oracle.c: sequential restatement of src/build_sketch.cpp + SuperMinHash/HLL addh"""
 
     def __init__(self):
-        self.lib = C.CDLL(str(ROOT / "oracle" / "liboracle.so"))
+        self.lib = C.CDLL(os.environ.get("ORACLE_LIB", str(ROOT / "oracle" / "liboracle.so")))   # ORACLE_LIB: a sanitizer build (scripts/asan_host.sh)
         L = self.lib
         L.orcb_smh_new.restype = C.c_void_p
         L.orcb_smh_new.argtypes = [C.c_size_t]
