@@ -546,6 +546,13 @@ void sigl_join_kernel(const uint32_t* __restrict__ sigP, const uint32_t* __restr
         for (int t = threadIdx.x; t < ib_hi - i_lo; t += WPB * kWave) hi_lds[t] = hi[i_lo + t];
     }
     __syncthreads();
+    // The candidate loads were issued before the tile's, and vector loads return in order: they have all arrived by now.  Say so
+    // to the compiler (an empty asm that consumes each register) -- otherwise its wait-count pass, which must assume the loop below
+    // can be entered with loads in flight, puts an `s_waitcnt vmcnt(k)` in front of every one of the 32 xors of EVERY row.
+#pragma unroll
+    for (int t = 0; t < T; ++t)
+#pragma unroll
+        for (int d = 0; d < ND; ++d) asm volatile("" :: "v"(c[t][d]));
     // ---- per wave (no block-wide synchronisation below)
     const int z0 = z0p1 ? z0p1 - 1 : n;
     if (k_base >= n) return;

@@ -359,6 +359,13 @@ def test_harder_workload_vs_oracle(oracle, algo):
         assert_same_pairs(got, want)
         s = sel.stats()
         assert s["survivors"] == st["survivors"] and s["evaluated"] == st["evaluated"]
+        # the same irregular pair graph (one huge near-clique of degenerate genomes beside the small clusters) through the
+        # label-ordered grouping and the chunk lanes
+        sel.set_param("group_label", 1)
+        for chunks in (0, 2, 5):
+            sel.set_pipeline(chunks)
+            assert_same_pairs(sel.run(cfg.tau, MODE_SMH, r, b, algo=algo), want)
+            assert sel.stats()["survivors"] == st["survivors"]
 
 
 @pytest.mark.parametrize("crit", [pkg.CRIT_HLL_A, pkg.CRIT_HLL_AN])
