@@ -415,8 +415,9 @@ hipError_t launch_joinl_w(selhip_ctx* c, const StageIO& io, int n_pad, const Row
     return hipGetLastError();
 }
 
-// (T = 2 groups of candidates per wave -- half the LDS reads -- was measured: 130 VGPRs, 3 waves per SIMD, cfg3 157 vs 127 us,
-// cfg4 2.37 vs 2.07 ms; the template keeps the parameter, only T = 1 is instantiated)
+// (T = 2 groups of candidates per wave -- half the LDS reads -- was measured twice: 130 VGPRs, 3 waves per SIMD, cfg3 157 vs 127 us,
+// cfg4 2.37 vs 2.07 ms; and, after the wait counts left the row loop, capped at 128 VGPRs / 4 waves per SIMD: cfg3 121 vs 101 us, cfg4
+// 2.28 vs 2.02 ms -- the join wants waves, not fewer LDS reads; the template keeps the parameter, only T = 1 is instantiated)
 template <int ND>
 hipError_t launch_joinl(selhip_ctx* c, const StageIO& io, int n_pad, const RowMap& rm) {
     return c->join_wpb == 8 ? launch_joinl_w<ND, 1, 8>(c, io, n_pad, rm) : launch_joinl_w<ND, 1, 4>(c, io, n_pad, rm);
