@@ -137,7 +137,7 @@ constexpr int kSketchSeg = 64;          // consecutive k-mer end positions rolle
 template <typename F>
 __device__ __forceinline__ void for_each_kmer(const uint8_t* __restrict__ codes, long long L, int k, F&& f) {
     const u64 kmask = k == 32 ? ~0ull : ((1ull << (2 * k)) - 1);
-    for (long long seg = (long long)(k - 1) + (long long)threadIdx.x * kSketchSeg; seg < L; seg += (long long)kBlock * kSketchSeg) {
+    for (long long seg = (long long)(k - 1) + (long long)threadIdx.x * kSketchSeg; seg < L; seg += (long long)blockDim.x * kSketchSeg) {
         const long long end = min(seg + kSketchSeg, L);
         u64 kmer = 0;
         int bases = 0;                                       // valid bases in the window, capped at k
@@ -150,7 +150,10 @@ __device__ __forceinline__ void for_each_kmer(const uint8_t* __restrict__ codes,
     }
 }
 
-__global__ __launch_bounds__(kBlock)
+// Block size: 256 or 1 024 threads (the host picks 1 024 when there are too few genomes to put several blocks on every CU: one
+// 4-wave block per CU is ONE wave per SIMD, and a lone wave issues a vector instruction every ~12 cycles -- rocprofv3 PMC, 256 genomes:
+// 2.57 ms at 0.98 waves per SIMD).
+__global__ __launch_bounds__(1024)
 void sketch_build_kernel(const uint8_t* __restrict__ codes_all, const long long* __restrict__ offsets, int k,
                          int m, int p_aux, uint8_t* __restrict__ hll_out, u64* __restrict__ smh_out,
                          uint8_t* __restrict__ aux_out) {
@@ -171,9 +174,9 @@ void sketch_build_kernel(const uint8_t* __restrict__ codes_all, const long long*
     const long long L = offsets[g + 1] - offsets[g];
     const uint32_t mask = (uint32_t)(m - 1);
 
-    for (int t = threadIdx.x; t < ms; t += kBlock) h[t] = ~0ull;
-    for (int t = threadIdx.x; t < 16384 / 4; t += kBlock) regs[t] = 0;
-    for (int t = threadIdx.x; t < (n_aux + 3) / 4; t += kBlock) aregs[t] = 0;
+    for (int t = threadIdx.x; t < ms; t += (int)blockDim.x) h[t] = ~0ull;
+    for (int t = threadIdx.x; t < 16384 / 4; t += (int)blockDim.x) regs[t] = 0;
+    for (int t = threadIdx.x; t < (n_aux + 3) / 4; t += (int)blockDim.x) aregs[t] = 0;
     if (threadIdx.x == 0) ctl[0] = 0;
     __syncthreads();
 
@@ -200,7 +203,7 @@ void sketch_build_kernel(const uint8_t* __restrict__ codes_all, const long long*
         while (true) {
             // a = max_b min(m-1, h[b] >> 32)    (bbmh.h:657-664: b_ / a_ bookkeeping, stated directly)
             int la = 0;
-            for (int t = threadIdx.x; t < ms; t += kBlock) la = max(la, (int)min((u64)(m - 1), h[t] >> 32));
+            for (int t = threadIdx.x; t < ms; t += (int)blockDim.x) la = max(la, (int)min((u64)(m - 1), h[t] >> 32));
             atomicMax(&ctl[0], la);
             __syncthreads();
             const int a = ctl[0];
@@ -209,7 +212,7 @@ void sketch_build_kernel(const uint8_t* __restrict__ codes_all, const long long*
             if (a <= J) break;
             if (a > kSketchJmaxParallel) {
                 // few k-mers per bucket: run the reference's sequential algorithm literally on one lane
-                for (int t = threadIdx.x; t < ms; t += kBlock) { h[t] = ~0ull; qq[t] = 0xFFFFFFFFu; pp[t] = 0; bb[t] = 0; }
+                for (int t = threadIdx.x; t < ms; t += (int)blockDim.x) { h[t] = ~0ull; qq[t] = 0xFFFFFFFFu; pp[t] = 0; bb[t] = 0; }
                 __syncthreads();
                 if (threadIdx.x == 0) {
                     bb[m - 1] = m;                                                    // bbmh.h:575
@@ -274,9 +277,9 @@ void sketch_build_kernel(const uint8_t* __restrict__ codes_all, const long long*
     }
     __syncthreads();
     uint32_t* out32 = reinterpret_cast<uint32_t*>(hll_out + g * 16384);
-    for (int t = threadIdx.x; t < 16384 / 4; t += kBlock) out32[t] = regs[t];
-    for (int t = threadIdx.x; t < n_aux; t += kBlock) aux_out[g * n_aux + t] = (uint8_t)(aregs[t >> 2] >> ((t & 3) * 8));
-    for (int t = threadIdx.x; t < ms; t += kBlock) smh_out[g * (long long)m + t] = h[t];
+    for (int t = threadIdx.x; t < 16384 / 4; t += (int)blockDim.x) out32[t] = regs[t];
+    for (int t = threadIdx.x; t < n_aux; t += (int)blockDim.x) aux_out[g * n_aux + t] = (uint8_t)(aregs[t >> 2] >> ((t & 3) * 8));
+    for (int t = threadIdx.x; t < ms; t += (int)blockDim.x) smh_out[g * (long long)m + t] = h[t];
 }
 
 __global__ __launch_bounds__(kBlock)

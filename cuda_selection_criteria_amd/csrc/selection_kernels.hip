@@ -1927,7 +1927,9 @@ int selhip_build_sketches(const uint8_t* d_codes, const int64_t* d_offsets, int6
     static hipError_t attr_err = hipSuccess;
     std::call_once(once, [] { attr_err = hipFuncSetAttribute((const void*)sketch_build_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); });
     HIPCHK(nullptr, attr_err);
-    hipLaunchKernelGGL(sketch_build_kernel, dim3((unsigned)n_genomes), dim3(kBlock), smem, (hipStream_t)hip_stream,
+    // one block per genome; few genomes: 16 waves per block, so that a CU that holds a single block still has 4 waves per SIMD
+    const unsigned threads = n_genomes < 2048 ? 1024u : (unsigned)kBlock;
+    hipLaunchKernelGGL(sketch_build_kernel, dim3((unsigned)n_genomes), dim3(threads), smem, (hipStream_t)hip_stream,
                        d_codes, (const long long*)d_offsets, k, m, p_aux, d_hll, (u64*)d_smh, d_aux_hll);
     HIPCHK(nullptr, hipGetLastError());
     return SELHIP_OK;
