@@ -442,23 +442,31 @@ void ertl_select_kernel(const uint32_t* __restrict__ counts, const u64* __restri
 // is the FIRST criterion; in the two-stage form (BASELINE config 5) the cheap smh_a join runs first and the
 // auxiliary criterion sees its survivors only: the selected set is the intersection either way.
 // ---------------------------------------------------------------------------------------------
+// One block lists up to kEnumSpan consecutive candidates of ONE row: the count is known from the row's cut-off, so the block
+// reserves its stretch of the list with a single atomic and writes it coalesced.  (The first form appended per wave through one
+// counter: 781 000 single-address atomics for cfg3's 5e7 pairs, 9.5 ms of a 15.5 ms `-c hll_a` pass -- the ~87 atomics/us wall of
+// DESIGN.md section 4.1 once more; now 0.2 ms.)
+constexpr int kEnumSpan = 16384;
+
 __global__ __launch_bounds__(kBlock)
 void enum_pairs_kernel(int n, const int* __restrict__ hi, const PassCounters* __restrict__ pc_in,
                        RowMap rm, int n_rows_grid,
                        selhip_int2_t* __restrict__ out, u64 out_cap, PassCounters* __restrict__ pc) {
-    __shared__ selhip_int2_t app_lds[kWavesPerBlock * kAppendCap];
+    __shared__ u64 base_lds;
     int i, i_e;
     rm.tile_rows((int)(blockIdx.x % n_rows_grid), 1, &i, &i_e);
     const int chunk = blockIdx.x / n_rows_grid;
     if (i >= i_e) return;
-    const int lane = threadIdx.x & (kWave - 1);
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
     const int kmin = max(i + 1, pc_in->z0p1 ? pc_in->z0p1 - 1 : n);
-    const int k = kmin + chunk * kBlock + (int)threadIdx.x;
-    WaveAppender app;
-    app.init(app_lds, wave, out, out_cap, &pc->n_aux_in);
-    app.push(k <= hi[i] && k < n, i, k, lane);
-    app.flush(lane);
+    const long long k0 = (long long)kmin + (long long)chunk * kEnumSpan;
+    const long long k_last = min((long long)min(hi[i], n - 1), k0 + kEnumSpan - 1);
+    const long long cnt = k_last - k0 + 1;
+    if (cnt <= 0) return;                                                     // block-uniform
+    if (threadIdx.x == 0) base_lds = atomicAdd(&pc->n_aux_in, (u64)cnt);      // exact total even when the list is too small
+    __syncthreads();
+    const u64 base = base_lds;
+    for (long long t = threadIdx.x; t < cnt; t += kBlock)
+        if (base + (u64)t < out_cap) out[base + (u64)t] = selhip_int2_t{i, (int)(k0 + t)};
 }
 
 // aux_fused_kernel<FMA, CRIT>: one LANE per pair; U = Ertl-MLE of the union histogram of the two AUXILIARY sketches.

@@ -875,7 +875,7 @@ int enqueue_pass(selhip_ctx* c) {
                 if (c->il_parts <= 1) { rm = row_map(c, (int)sb, (int)se); }
                 else { rm.row_begin = (int)sb; rm.row_end = (int)se; }            // sb - rb is a multiple of the interleave period
                 const long long rows = rm.n_tiles(1);
-                const long long blocks = rows * ((n + kBlock - 1) / kBlock);
+                const long long blocks = rows * ((n + kEnumSpan - 1) / kEnumSpan);
                 if (blocks > 0x7FFFFFFFll) { set_err(&c->err, "row range too large"); return SELHIP_E_BADARG; }
                 if (blocks > 0) {
                     hipLaunchKernelGGL(enum_pairs_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, c->stream, n, c->hi.p, pc0,
