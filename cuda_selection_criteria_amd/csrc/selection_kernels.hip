@@ -150,8 +150,8 @@ struct selhip_ctx {
     size_t scan_tmp_stride = 0;         // bytes of rocPRIM scan scratch per chunk
     PassCounters* h_pc = nullptr;       // pinned host mirror of the kMaxChunks + 1 counter blocks
     // stage pipeline: stage 1 of row chunk c+1 (VALU-bound) overlaps stage 2 of chunk c (memory/LDS-bound)
-    hipStream_t st_stage1 = nullptr, st_stage2 = nullptr;     // internal non-blocking streams
-    hipEvent_t ev_start = nullptr, ev_end = nullptr, ev_chunk[8] = {};
+    hipStream_t st_stage1 = nullptr;    // internal non-blocking stream: the second chunk lane (the first is `stream`)
+    hipEvent_t ev_start = nullptr, ev_end = nullptr;       // fork / join of the second lane
     int n_chunks_last = 1;
     int pipeline = -1;                  // -1 auto, 0 off, >0 forced chunk count
     int64_t cand_begin = 0;             // candidates restricted to ranks >= cand_begin (selhip_ctx_set_candidate_begin)
@@ -909,10 +909,8 @@ int ensure_scratch(selhip_ctx* c, size_t surv_cap, size_t res_cap) {
     HIPCHK(&c->err, c->seg_cnt.ensure(kSegCounterSlots));
     if (!c->st_stage1) {
         HIPCHK(&c->err, hipStreamCreateWithFlags(&c->st_stage1, hipStreamNonBlocking));
-        HIPCHK(&c->err, hipStreamCreateWithFlags(&c->st_stage2, hipStreamNonBlocking));
         HIPCHK(&c->err, hipEventCreateWithFlags(&c->ev_start, hipEventDisableTiming));
         HIPCHK(&c->err, hipEventCreateWithFlags(&c->ev_end, hipEventDisableTiming));
-        for (int k = 0; k < kMaxChunks; ++k) HIPCHK(&c->err, hipEventCreateWithFlags(&c->ev_chunk[k], hipEventDisableTiming));
     }
     HIPCHK(&c->err, c->surv.ensure(surv_cap));
     HIPCHK(&c->err, c->cand.ensure(surv_cap));
@@ -1021,9 +1019,8 @@ void selhip_ctx_destroy(selhip_ctx* c) {
     c->csr_cnt.release(); c->csr_start.release(); c->grouped.release(); c->scan_tmp.release();
     if (c->h_pc) (void)hipHostFree(c->h_pc);
     if (c->st_stage1) {
-        (void)hipStreamDestroy(c->st_stage1); (void)hipStreamDestroy(c->st_stage2);
+        (void)hipStreamDestroy(c->st_stage1);
         (void)hipEventDestroy(c->ev_start); (void)hipEventDestroy(c->ev_end);
-        for (int k = 0; k < kMaxChunks; ++k) (void)hipEventDestroy(c->ev_chunk[k]);
     }
     delete c;
 }
