@@ -474,10 +474,22 @@ void enum_pairs_kernel(int n, const int* __restrict__ hi, const PassCounters* __
 //   CRIT 2 (hll_an): J = ((double)(e_i+e_k) - U)/U;  C = min(1, (1+Z*sigma_p)*e_k/U) * (1+gamma) * S;  J + C >= tau
 // zs = (double)(float)(Z*sigma_p) and S (= zs for order_n = 1) are computed on the host in float/double exactly as
 // criteria_sketch.hpp:7-20,25-31,39-40 do.  FMA flavour: g++ fuses (1+gamma)*card_B - t_hat_mas (criteria_sketch.hpp:41).
+// The lane's histogram column packs TWO bins per dword (bin k in half k & 1 of word k >> 1): a count is at most 2^p_aux <= 4096, and
+// the adds of one instruction still go to 64 different dwords (one per lane).  8 KiB per one-wave block instead of 16: twice the
+// resident waves, which is what the kernel is short of -- most of a wave's life is the serial f64 solve, not the binning
+// (cfg3's 5e7 pairs with hll_a as first criterion: 5.4 -> 4.8 ms; the kernel is then held at 4 waves per SIMD by its 114 VGPRs).
 struct LdsColumn {
     const uint32_t* base;       // &hist[lane]
-    __device__ __forceinline__ uint32_t operator[](int k) const { return base[k * kWave]; }
+    __device__ __forceinline__ uint32_t operator[](int k) const { return (base[(k >> 1) * kWave] >> ((k & 1) << 4)) & 0xFFFFu; }
 };
+
+__device__ __forceinline__ void hist_add_word_packed(uint32_t* __restrict__ col, uint32_t w) {
+#pragma unroll
+    for (int s = 0; s < 32; s += 8) {
+        const uint32_t v = (w >> s) & 63u;        // register values are <= 64-p+1 < 64
+        __hip_atomic_fetch_add(col + (v >> 1) * kWave, 1u << ((v & 1u) << 4), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+}
 
 // One LANE per pair, histogram and estimator fused: the auxiliary sketches are small (2^p_aux <= 4096 registers), so a lane
 // reads its pair's two rows itself (16-B loads), bins the per-byte max into ITS column of the wave's [bin][lane] LDS
@@ -491,17 +503,14 @@ void aux_fused_kernel(const uint8_t* __restrict__ aux_hll, int p_aux, const selh
                       const u64* __restrict__ n_dev, u64 cap, double relerr_scaled, const u64* __restrict__ ecard, double tau,
                       double zs, double S_sum,
                       selhip_int2_t* __restrict__ out, u64 out_cap, u64* __restrict__ out_count) {
-    __shared__ __attribute__((aligned(16))) uint32_t hist[64 * kWave];     // declared first: LDS offset 0 (fast address path)
+    __shared__ __attribute__((aligned(16))) uint32_t hist[32 * kWave];     // [bin pair][lane], 8 KiB
     __shared__ selhip_int2_t app_lds[kAppendCap];
     const int lane = threadIdx.x;
     u64 n = *n_dev;
     if (n > cap) n = cap;
     const long long nreg = 1ll << p_aux;
     const int n16 = (int)(nreg >> 4);                                        // 16-byte groups per row (p_aux >= 4)
-    const bool lds_at_zero = (uint32_t)(uintptr_t)hist == 0u;
     uint32_t* const col = hist + lane;
-    uint32_t a0 = (uint32_t)lane * 4u, a1 = a0, a2 = a0, a3 = a0;
-    constexpr uint32_t kMask = 0x3F3F3F3Fu;
     WaveAppender app;
     app.init(app_lds, 0, out, out_cap, out_count);
     for (u64 base = (u64)blockIdx.x * kWave; base < n; base += (u64)gridDim.x * kWave) {
@@ -511,7 +520,7 @@ void aux_fused_kernel(const uint8_t* __restrict__ aux_hll, int p_aux, const selh
         u64 ea = 0, eb = 1;
         if (live) { pr = pairs[j]; ea = ecard[pr.x]; eb = ecard[pr.y]; }
 #pragma unroll 8
-        for (int k = 0; k < 64; ++k) col[k * kWave] = 0;
+        for (int k = 0; k < 32; ++k) col[k * kWave] = 0;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         const uint4* ra = reinterpret_cast<const uint4*>(aux_hll + (long long)pr.x * nreg);
         const uint4* rb = reinterpret_cast<const uint4*>(aux_hll + (long long)pr.y * nreg);
@@ -523,17 +532,10 @@ void aux_fused_kernel(const uint8_t* __restrict__ aux_hll, int p_aux, const selh
 #pragma unroll
             for (int t = 0; t < 8; ++t) {
                 if (c0 + t < n16) {
-                    if (lds_at_zero) {
-                        hist_add_max_word(a0, a1, a2, a3, xa[t].x & kMask, xb[t].x & kMask);
-                        hist_add_max_word(a0, a1, a2, a3, xa[t].y & kMask, xb[t].y & kMask);
-                        hist_add_max_word(a0, a1, a2, a3, xa[t].z & kMask, xb[t].z & kMask);
-                        hist_add_max_word(a0, a1, a2, a3, xa[t].w & kMask, xb[t].w & kMask);
-                    } else {
-                        hist_add_word(col, max_u8x4(xa[t].x, xb[t].x));
-                        hist_add_word(col, max_u8x4(xa[t].y, xb[t].y));
-                        hist_add_word(col, max_u8x4(xa[t].z, xb[t].z));
-                        hist_add_word(col, max_u8x4(xa[t].w, xb[t].w));
-                    }
+                    hist_add_word_packed(col, max_u8x4(xa[t].x, xb[t].x));
+                    hist_add_word_packed(col, max_u8x4(xa[t].y, xb[t].y));
+                    hist_add_word_packed(col, max_u8x4(xa[t].z, xb[t].z));
+                    hist_add_word_packed(col, max_u8x4(xa[t].w, xb[t].w));
                 }
             }
         }
