@@ -229,6 +229,8 @@ void csr_scan_fill_kernel(const int* __restrict__ cnt, int n, const selhip_int2_
 //    (the compiler's own sequence -- max, shift, mask, add -- is kept as the path for a histogram not at offset 0);
 //  * (binning a pair in two halves with the other half's loads in flight -- same registers, no wait on memory inside a
 //    wave -- changed nothing at cfg3 and cost 10 % at cfg4: the kernel waits on the LDS, not on memory);
+//  * (non-temporal loads for the candidate rows -- each is used by one pair of this wave only -- were measured: 149 instead of 115 us
+//    at cfg3, +8 / +15 % at cfg4 / cfg5: the rows ARE reused through L2 by the other waves of the bucket's neighbourhood);
 //  * the histogram is zeroed once per wave: bins only grow, and a pair's counts are the difference of the running column
 //    sums before and after it (unsigned arithmetic: wrap-around cancels), which removes 64 LDS stores per pair.
 constexpr int kHistSpanBlocks = 16384;      // one-wave blocks (a multiple of 8); ~8 resident per CU, the rest balance the tail
