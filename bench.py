@@ -375,6 +375,13 @@ def main():
             out["roofline"] = {"bound": "salu_issue" if not used_sig else "n/a", "kernel": dom_name, "avg_launch_ms": dom_ms,
                                "launches_per_step": launches, "traffic": traffic, "traffic_source": traffic_src,
                                "achieved": None, "peak": None, "unit": "G instr/s", "frac": None}
+            if not used_sig and cfg.m % 128 == 0 and (n_rows & (n_rows - 1)) == 0 and dom_ms > 0:
+                try:                                             # the literal stream kernel as the main algorithm: its issue roofline
+                    r_ = stream_issue_roofline(cfg.m, n_rows, pairs_rank0 / launches, dom_ms)
+                    if r_:
+                        out["roofline"].update(r_)
+                except Exception:
+                    pass
         out["hbm_algorithmic"] = {"bytes_per_pair": 8 * cfg.m, "achieved_GBs": achieved_hbm, "peak_GBs": HBM_PEAK_GBS,
                                   "ratio": (achieved_hbm / HBM_PEAK_GBS) if achieved_hbm else None,
                                   "note": "SURVEY.md 8(d) nominal: one candidate sketch streamed per pair-comparison.  NOT a bound of this design: "
