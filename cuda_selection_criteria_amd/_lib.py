@@ -90,6 +90,8 @@ HIP_SYMBOLS = {
     "selhip_ctx_set_candidate_begin": (_i, [_vp, _i64]),
     "selhip_smh_a_pairs": (_i, [_vp, _i, _i, _i, _vp, _i64, _vp, _vp]),
     "selhip_hll_union_hist": (_i, [_vp, _i, _vp, _i64, _vp, _vp]),
+    "selhip_hll_bitslice": (_i, [_vp, _i64, _vp, _vp, _vp, _vp]),
+    "selhip_hll_union_hist_planes": (_i, [_vp, _vp, _i, _vp, _i64, _vp, _vp]),
     "selhip_ertl_estimate": (_i, [_vp, _i64, _i, _i, _vp, _vp]),
     "selhip_smh_match_counts": (_i, [_vp, _i, _vp, _i64, _vp, _vp]),
     "selhip_synth_generate": (_i, [C.POINTER(Synth), _i64, _i64, _vp, _vp, _vp, _vp]),

@@ -181,6 +181,22 @@ void csr_fill_kernel(const selhip_int2_t* __restrict__ pairs, const u64* __restr
     }
 }
 
+// The label order in TWO launches for n <= kSmallScanMax (the four above cost ~10 us more than the plain order at cfg3):
+//   csr_label_offsets_kernel: per row its root and, from the SAME atomic that accumulates the group's size, the offset of its bucket
+//                             inside the group  (off[i] = atomicAdd(&gsum[root(i)], cnt[i]): the old value is the offset);
+//   csr_label_scan_fill_kernel: every block scans the group sizes into its own LDS copy (as csr_scan_fill_kernel does with the row
+//                             counts) and scatters its share of the pairs to gbase[root(x)] + off[x] + (cursor of row x).
+__global__ __launch_bounds__(kBlock)
+void csr_label_offsets_kernel(const int* __restrict__ cnt, const int* __restrict__ lab, int n, int* __restrict__ gsum,
+                              int* __restrict__ root, int* __restrict__ off) {
+    const int i = (int)(blockIdx.x * kBlock + threadIdx.x);
+    if (i >= n) return;
+    const int c = cnt[i];
+    const int r = csr_label_of(lab, i, n);
+    root[i] = r;
+    off[i] = c ? atomicAdd(&gsum[r], c) : 0;
+}
+
 // (The three steps as ONE single-block launch with the group sums in LDS, for N <= 32 768, were built and measured at cfg3: grouping
 // 9.5 -> 20 us (five dependent memory round trips on one CU), stage 2a 114 -> 106 us, step 0.311 -> 0.313 ms -- dropped; sets that fit
 // the Infinity Cache keep the query-row order.)
@@ -216,6 +232,38 @@ void csr_scan_fill_kernel(const int* __restrict__ cnt, int n, const selhip_int2_
     for (u64 j = (u64)blockIdx.x * 1024 + threadIdx.x; j < np; j += (u64)gridDim.x * 1024) {
         const selhip_int2_t pr = pairs[j];
         const u64 pos = (u64)csr_start_lds[pr.x] + (u64)atomicAdd(&fill[pr.x], 1);
+        if (pos < cap) grouped[pos] = pr;
+    }
+}
+
+__global__ __launch_bounds__(1024)
+void csr_label_scan_fill_kernel(const int* __restrict__ gsum, int n, const int* __restrict__ root, const int* __restrict__ off,
+                                const selhip_int2_t* __restrict__ pairs, const u64* __restrict__ n_dev,
+                                u64 cap, int* __restrict__ fill, selhip_int2_t* __restrict__ grouped) {
+    extern __shared__ int csr_start_lds[];                                  // n ints: start of every label group
+    __shared__ int wave_sum[16];
+    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+    const int per = (n + 1023) / 1024;                                      // <= 32
+    const int i0 = threadIdx.x * per, i1 = min(i0 + per, n);
+    int v[32];
+    int mine = 0;
+#pragma unroll
+    for (int t = 0; t < 32; ++t) { v[t] = (t < per && i0 + t < i1) ? gsum[i0 + t] : 0; mine += v[t]; }
+    int inc = mine;
+#pragma unroll
+    for (int s = 1; s < kWave; s <<= 1) { const int o = __shfl_up(inc, s, kWave); if (lane >= s) inc += o; }
+    if (lane == kWave - 1) wave_sum[wave] = inc;
+    __syncthreads();
+    int run = inc - mine;
+    for (int w = 0; w < wave; ++w) run += wave_sum[w];
+#pragma unroll
+    for (int t = 0; t < 32; ++t) { if (t < per && i0 + t < i1) csr_start_lds[i0 + t] = run; run += v[t]; }
+    __syncthreads();
+    u64 np = *n_dev;
+    if (np > cap) np = cap;
+    for (u64 j = (u64)blockIdx.x * 1024 + threadIdx.x; j < np; j += (u64)gridDim.x * 1024) {
+        const selhip_int2_t pr = pairs[j];
+        const u64 pos = (u64)csr_start_lds[root[pr.x]] + (u64)off[pr.x] + (u64)atomicAdd(&fill[pr.x], 1);
         if (pos < cap) grouped[pos] = pr;
     }
 }

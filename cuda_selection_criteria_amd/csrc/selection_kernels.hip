@@ -13,6 +13,7 @@
 //                                             v_cmp_eq_u64 lane masks folded on the scalar unit; smh_generic_kernel
 //   kernel_sigjoin.cuh  sig_build / sig_join / verify   stage 1 ALGO_SIG: all-pairs band-signature join (DPP broadcast) + exact verify
 //   kernel_hll.cuh      hll_union_hist_kernel, ertl_select_kernel (stage 2), enum_pairs / aux_fused (hll_a, hll_an)
+//   kernel_hllbs.cuh    hll_bitslice_kernel, hll_union_hist_bs_kernel: stage 2a on bit-sliced registers (bit-serial max, decode tree, v_bcnt)
 //   kernel_pairlist.cuh explicit pair lists (drop-in launch_kernel_* path, test building blocks)
 //   kernel_sketch.cuh   synth_kernel, sketch_build_kernel (build_sketch on the GPU), permute_rows
 //
@@ -43,6 +44,7 @@
 #include "kernel_stream.cuh"
 #include "kernel_sigjoin.cuh"
 #include "kernel_hll.cuh"
+#include "kernel_hllbs.cuh"
 #include "kernel_pairlist.cuh"
 #include "kernel_sketch.cuh"
 
@@ -158,6 +160,14 @@ struct selhip_ctx {
     int il_block = 128, il_parts = 1, il_part = 0;    // row interleave (selhip_ctx_set_row_interleave); il_parts 1 = contiguous
     int hist_pad = 0;                   // stage 2a: extra LDS bytes per one-wave block (lowers the number of resident waves per CU)
     int hist_run = 0, hist_blocks = kHistSpanBlocks;   // stage 2a: pairs per task (0 = automatic: 1, or 4 with the label order), one-wave blocks (multiple of 8)
+    // stage 2a on bit planes (kernel_hllbs.cuh): the p = 14 registers of every genome as 6 bit planes, written when the sketches
+    // are uploaded / attached (selhip_ctx_upload / _attach; the caller's arrays must not change behind an attached context)
+    DevBuf<uint32_t> hll_bs;            // [n][6][512]
+    DevBuf<uint8_t> hll_gmax;           // [n] largest register value of each genome
+    DevBuf<int> hll_bs_max;             // largest register value of the set (device side)
+    int hll_khi = 0;                    // 0 = no planes; else max register value + 1
+    int hist_algo = -1;                 // -1 automatic (bit planes when p = 14), 0 = byte rows + LDS histogram (hll_union_hist_runs_kernel), 1 = bit planes
+    int hist_bs_blocks = 2048;          // bit-plane kernel: 4-wave blocks (multiple of 8)
     int group_label = -1;               // grouping: lay the query-row buckets out by label (kernel_hll.cuh): -1 = automatic (HLL rows beyond kLabelOrderBytes), 0 off, 1 on
     int verify_fb = 0;                  // test hook: force the collision fallback of verify16_kernel
     int join_wpb = 4;                   // 16-bit join: waves per block (DPP form: 1 or 4; LDS form: 4 or 8 -- the waves of a block share the staged query tile)
@@ -534,6 +544,32 @@ unsigned grid_for(u64 items, unsigned per_block, unsigned max_blocks) {
     return (unsigned)b;
 }
 
+// ---- stage 2a on bit planes (kernel_hllbs.cuh) -------------------------------------------------
+// the instantiation for a set whose largest register value is khi - 1 = the number of bit planes that can be non-zero
+hipError_t launch_hist_bs(int khi, unsigned blocks, hipStream_t st, const uint32_t* bs, const uint8_t* gmax, const selhip_int2_t* list, const u64* count,
+                          u64 cap, uint32_t* counts, u64 off, u64 window, int run) {
+#define SELHIP_BS_LAUNCH(NB) hipLaunchKernelGGL((hll_union_hist_bs_kernel<NB>), dim3(blocks), dim3(kBlock), 0, st, bs, gmax, list, count, cap, counts, off, window, run)
+    if (khi <= 16)      SELHIP_BS_LAUNCH(4);
+    else if (khi <= 32) SELHIP_BS_LAUNCH(5);
+    else                SELHIP_BS_LAUNCH(6);
+#undef SELHIP_BS_LAUNCH
+    return hipGetLastError();
+}
+
+// writes the bit planes of n genomes and returns max register value + 1 through *khi (waits for the stream)
+int build_bitslices(std::string* err, hipStream_t st, const uint8_t* d_hll, int64_t n, uint32_t* d_bs, uint8_t* d_gmax, int* d_max, int* khi) {
+    HIPCHK(err, hipMemsetAsync(d_max, 0, sizeof(int), st));
+    hipLaunchKernelGGL(hll_bitslice_kernel, dim3(grid_for((u64)n, kWavesPerBlock, 8192)), dim3(kBlock), 0, st, d_hll, (long long)n, d_bs, d_gmax, d_max);
+    HIPCHK(err, hipGetLastError());
+    int mx = 0;
+    HIPCHK(err, hipMemcpyAsync(&mx, d_max, sizeof(int), hipMemcpyDeviceToHost, st));
+    HIPCHK(err, hipStreamSynchronize(st));
+    *khi = mx + 1;
+    return SELHIP_OK;
+}
+
+bool use_bitslices(const selhip_ctx* c) { return c->p == 14 && c->hll_khi > 0 && c->hist_algo != 0; }
+
 int compute_cards(selhip_ctx* c, const uint8_t* d_hll, int64_t n, int p, double* d_out) {
     if (n <= 0) return SELHIP_OK;
     HIPCHK(&c->err, c->self_pairs.ensure((size_t)n));
@@ -641,14 +677,16 @@ struct Chain {
     uint32_t* counts; u64 window;           // histogram scratch: `window` pairs at a time
 };
 
-// per-chain row arrays of the grouping: counts | fill cursors | labels | label-group sums (then bucket starts), n ints each
-size_t csr_stride(int n) { return 4 * (size_t)n + 2; }
+// per-chain row arrays of the grouping: counts | fill cursors | labels | label-group sums (then bucket starts) | roots, n ints each
+size_t csr_stride(int n) { return 5 * (size_t)n + 2; }
 
 constexpr double kLabelOrderPairs = 4e8;
 constexpr size_t kLabelOrderBytes = (size_t)192 << 20;     // HLL rows beyond this (the Infinity Cache holds 256 MiB): label order
 bool label_order(const selhip_ctx* c) {
     if (!(c->p == 14 && c->group_stage2)) return false;
     if (c->group_label >= 0) return c->group_label == 1;
+    // the bit-plane kernel is bound by its fetches from beyond L2 at every size (cfg3: stage 2a 79 -> 54 us with the label order)
+    if (use_bitslices(c)) return true;
     // its three extra launches (~15 us) only pay where stage 2a is bound by fetches from beyond L2 AND has enough pairs: HLL rows
     // beyond the Infinity Cache and -- the proxy known here -- a large pair space (one of 8 ranks of cfg4, 1.6e8 pairs: 0.515 -> 0.529 ms
     // with it; one of 8 ranks of cfg5, 6.2e8: 1.613 -> 1.577 ms; cfg3, whose rows fit the Infinity Cache: 0.311 -> 0.313 ms)
@@ -670,7 +708,16 @@ int enqueue_tail(selhip_ctx* c, const Chain& ch, const selhip_int2_t* final_list
             hipLaunchKernelGGL(csr_count_kernel, dim3(512), dim3(kBlock), 0, st, final_list, final_count, final_cap, cnt, label ? lab : nullptr, n);
             HIPCHK(&c->err, hipGetLastError());
         }
-        if (label) {
+        if (label && n <= kSmallScanMax) {
+            int* const root = cnt + 4 * (size_t)n;
+            hipLaunchKernelGGL(csr_label_offsets_kernel, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, cnt, lab, n, gsum, root, ch.csr_start);
+            HIPCHK(&c->err, hipGetLastError());
+            if ((size_t)n * sizeof(int) > 48 * 1024)
+                HIPCHK(&c->err, hipFuncSetAttribute((const void*)csr_label_scan_fill_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kSmallScanMax * 4));
+            hipLaunchKernelGGL(csr_label_scan_fill_kernel, dim3(256), dim3(1024), (size_t)n * sizeof(int), st, gsum, n, root, ch.csr_start,
+                               final_list, final_count, final_cap, fill, ch.grouped);
+            HIPCHK(&c->err, hipGetLastError());
+        } else if (label) {
             const unsigned row_blocks = (unsigned)((n + kBlock - 1) / kBlock);
             hipLaunchKernelGGL(csr_label_sum_kernel, dim3(row_blocks), dim3(kBlock), 0, st, cnt, lab, n, gsum);
             HIPCHK(&c->err, hipGetLastError());
@@ -698,7 +745,10 @@ int enqueue_tail(selhip_ctx* c, const Chain& ch, const selhip_int2_t* final_list
     for (u64 off = 0; off < final_cap; off += ch.window) {
         {
             TimerScope t(c, T_HIST, st);
-            if (c->p == 14)
+            if (use_bitslices(c))
+                HIPCHK(&c->err, launch_hist_bs(c->hll_khi, (unsigned)c->hist_bs_blocks, st, c->hll_bs.p, c->hll_gmax.p, final_list, final_count, final_cap, ch.counts, off, ch.window,
+                                               c->hist_run > 0 ? c->hist_run : (grouped ? 4 : 1)));
+            else if (c->p == 14)
                 hipLaunchKernelGGL(hll_union_hist_runs_kernel, dim3(c->hist_blocks), dim3(kWave), (size_t)c->hist_pad, st,
                                    c->d_hll, final_list, final_count, final_cap, ch.counts, off, ch.window,
                                    c->hist_run > 0 ? c->hist_run : (grouped && label_order(c) ? 4 : 1));
@@ -1017,6 +1067,7 @@ void selhip_ctx_destroy(selhip_ctx* c) {
     c->aux_il.release(); c->cand.release(); c->sigQ.release(); c->sigT.release(); c->sigP.release(); c->sigG.release(); c->fin.release(); c->own_aux_hll.release();
     c->hj_keys_in.release(); c->hj_keys_out.release(); c->hj_vals_in.release(); c->hj_vals_out.release(); c->hj_tmp.release();
     c->csr_cnt.release(); c->csr_start.release(); c->grouped.release(); c->scan_tmp.release();
+    c->hll_bs.release(); c->hll_bs_max.release(); c->hll_gmax.release();
     if (c->h_pc) (void)hipHostFree(c->h_pc);
     if (c->st_stage1) {
         (void)hipStreamDestroy(c->st_stage1);
@@ -1094,6 +1145,18 @@ int selhip_ctx_set_param(selhip_ctx* c, const char* name, int value) {
         c->hist_pad = value;
         return SELHIP_OK;
     }
+    if (!std::strcmp(name, "hist_algo")) {
+        // takes effect at the next selhip_ctx_upload / _attach (the bit planes are written there)
+        if (value < -1 || value > 1) { set_err(&c->err, "hist_algo must be -1 (automatic), 0 (byte rows, LDS histogram) or 1 (bit planes)"); return SELHIP_E_BADARG; }
+        c->hist_algo = value;
+        if (value == 0) c->hll_khi = 0;
+        return SELHIP_OK;
+    }
+    if (!std::strcmp(name, "hist_bs_blocks")) {
+        if (value < 8 || value > 65536 || value % 8) { set_err(&c->err, "hist_bs_blocks must be a multiple of 8 in [8, 65536]"); return SELHIP_E_BADARG; }
+        c->hist_bs_blocks = value;
+        return SELHIP_OK;
+    }
     if (!std::strcmp(name, "hist_blocks")) {
         if (value < 8 || value > 65536 || value % 8) { set_err(&c->err, "hist_blocks must be a multiple of 8 in [8, 65536]"); return SELHIP_E_BADARG; }
         c->hist_blocks = value;
@@ -1155,7 +1218,16 @@ static int validate_shape(selhip_ctx* c, int64_t n, int m, int p) {
 
 static int after_sketches(selhip_ctx* c, const double* cards_src, bool cards_on_host) {
     // cards: given or computed with the device estimator
+    c->hll_khi = 0;
     if (c->n == 0) return SELHIP_OK;
+    if (c->p == 14 && c->hist_algo != 0) {
+        // the registers once more as bit planes: what stage 2a reads (12 KiB per genome; the byte rows stay for report() and the callers)
+        HIPCHK(&c->err, c->hll_bs.ensure((size_t)c->n * kBsGenomeDwords));
+        HIPCHK(&c->err, c->hll_bs_max.ensure(1));
+        HIPCHK(&c->err, c->hll_gmax.ensure((size_t)c->n));
+        const int rc = build_bitslices(&c->err, c->stream, c->d_hll, c->n, c->hll_bs.p, c->hll_gmax.p, c->hll_bs_max.p, &c->hll_khi);
+        if (rc) return rc;
+    }
     if (!cards_src) {
         HIPCHK(&c->err, c->own_cards.ensure((size_t)c->n));
         int rc = compute_cards(c, c->d_hll, c->n, c->p, c->own_cards.p);
@@ -1446,6 +1518,32 @@ int selhip_hll_union_hist(const uint8_t* d_hll, int p, const selhip_int2_t* d_pa
     hipLaunchKernelGGL(hll_union_hist_kernel, dim3(grid_for((u64)n_pairs, kWavesPerBlock, 4096)), dim3(kBlock), 0,
                        (hipStream_t)hip_stream, d_hll, p, d_pairs, (const u64*)nullptr, (u64)n_pairs, (u64)n_pairs, d_counts);
     HIPCHK(nullptr, hipGetLastError());
+    return SELHIP_OK;
+}
+
+int selhip_hll_bitslice(const uint8_t* d_hll, int64_t n, uint32_t* d_planes, uint8_t* d_gmax, int* khi_out, void* hip_stream) {
+    if (!d_hll || !d_planes || !d_gmax || !khi_out || n < 0) return SELHIP_E_BADARG;
+    *khi_out = 1;
+    if (n == 0) return SELHIP_OK;
+    int* d_max = nullptr;
+    HIPCHK(nullptr, hipMalloc((void**)&d_max, sizeof(int)));
+    const int rc = build_bitslices(nullptr, (hipStream_t)hip_stream, d_hll, n, d_planes, d_gmax, d_max, khi_out);
+    (void)hipFree(d_max);
+    return rc;
+}
+
+int selhip_hll_union_hist_planes(const uint32_t* d_planes, const uint8_t* d_gmax, int khi, const selhip_int2_t* d_pairs, int64_t n_pairs,
+                                 uint32_t* d_counts, void* hip_stream) {
+    if (!d_planes || !d_gmax || !d_pairs || !d_counts || n_pairs < 0 || khi < 1 || khi > 64) return SELHIP_E_BADARG;
+    if (n_pairs == 0) return SELHIP_OK;
+    u64* d_n = nullptr;
+    HIPCHK(nullptr, hipMalloc((void**)&d_n, sizeof(u64)));
+    const u64 np = (u64)n_pairs;
+    hipError_t e = hipMemcpyAsync(d_n, &np, sizeof(u64), hipMemcpyHostToDevice, (hipStream_t)hip_stream);
+    if (e == hipSuccess) e = launch_hist_bs(khi, 2048, (hipStream_t)hip_stream, d_planes, d_gmax, d_pairs, d_n, np, d_counts, 0, ~0ull, 1);
+    if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)hip_stream);
+    (void)hipFree(d_n);
+    HIPCHK(nullptr, e);
     return SELHIP_OK;
 }
 

@@ -148,8 +148,11 @@ int selhip_ctx_set_candidate_begin(selhip_ctx* ctx, int64_t k_min);
  *   "join_db"     1 (default) / 0: double-buffered query batches in the DPP form of the 16-bit join
  *   "join_wpb"    waves per block of the 16-bit join: LDS form 4 (default) or 8, DPP form 1 or 4
  *   "sig_tile"    1 (default): signature build 16 genomes per block with an LDS transpose; 0: one thread per bucket
- *   "hist_run"    pairs a wave of stage 2a takes at a time (0 = automatic: 1, or 4 with the label order);
- *   "hist_blocks" its one-wave blocks (multiple of 8);
+ *   "hist_algo"   stage 2a: -1 (default) / 1 = on the registers' bit planes, written at upload / attach (hll_union_hist_bs_kernel:
+ *                 bit-serial max, decode tree, population counts; p = 14 only); 0 = on the byte rows with a lane-private LDS
+ *                 histogram (hll_union_hist_runs_kernel).  Takes effect at the next upload / attach.
+ *   "hist_run"    pairs a wave of stage 2a takes at a time (0 = automatic: 4 on a grouped list; the byte-row kernel: 1, or 4 with the label order);
+ *   "hist_blocks" one-wave blocks of the byte-row kernel, "hist_bs_blocks" four-wave blocks of the bit-plane kernel (multiples of 8);
  *   "group_label" stage-2 grouping lays the query-row buckets out by label = a row's smallest partner, so that the pairs of a
  *                 cluster of similar genomes are neighbours in the list and their HLL rows stay in L2 (-1 = automatic: sets
  *                 whose HLL rows exceed 192 MiB and passes of >= 4e8 pairs; 0 off; 1 on);
@@ -285,6 +288,13 @@ int selhip_smh_a_pairs(const uint64_t* d_aux, int m, int n_rows, int n_bands,
 /* union histogram of an explicit pair list: d_counts[j][64] (u32) = counts of max(reg_x, reg_y). */
 int selhip_hll_union_hist(const uint8_t* d_hll, int p, const selhip_int2_t* d_pairs, int64_t n_pairs,
                           uint32_t* d_counts, void* hip_stream);
+/* The p = 14 registers of n genomes as bit planes, the layout stage 2a reads (csrc/kernel_hllbs.cuh): d_planes[n][6][512] u32,
+ * plane b of a genome = bit b of its 16 384 registers; d_gmax[n] u8 = every genome's largest register value; *khi_out = the
+ * set's largest register value + 1.  Waits for the stream. */
+int selhip_hll_bitslice(const uint8_t* d_hll, int64_t n_genomes, uint32_t* d_planes, uint8_t* d_gmax, int* khi_out, void* hip_stream);
+/* union histograms from the bit planes (same result as selhip_hll_union_hist with p = 14); gmax / khi as returned above.  Waits. */
+int selhip_hll_union_hist_planes(const uint32_t* d_planes, const uint8_t* d_gmax, int khi, const selhip_int2_t* d_pairs, int64_t n_pairs,
+                                 uint32_t* d_counts, void* hip_stream);
 /* Ertl-MLE of n histograms: d_est[j] = ertl_ml_estimate(d_counts[j], p, 64-p, 1e-2). */
 int selhip_ertl_estimate(const uint32_t* d_counts, int64_t n, int p, int fp_mode, double* d_est, void* hip_stream);
 /* bucket-match counts (the by-product the north_star mentions): d_matches[j] = #{b : aux_x[b]==aux_y[b]} */

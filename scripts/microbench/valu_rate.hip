@@ -23,7 +23,8 @@
 enum Kind { K_FMA_F32, K_ADD_U32, K_XOR_B32, K_PK_MIN_U16, K_XOR_DPP, K_MIN3_U32, K_PK_FMA_F32, K_OR3_B32, K_JOINMIX, K_JOINMIX_DEP,
             K_SAD_U16, K_PERM_B32, K_CMP_EQ_U32, K_FMA_F64, K_MQSAD_U32_U8, K_MUL_LO_U32, K_PK_ADD_U16,
             K_MIN_U32, K_AND_B32, K_XOR_SGPR, K_LSHRREV_B32, K_MOV_DPP, K_AND_OR_B32, K_BFI_B32, K_JOINMIX_SGPR, K_MIN_U16, K_XOR_SDWA, K_ADD_F32, K_MAX_U32,
-            K_MIX_ALT, K_MIX_G4, K_MIX_G8, K_MIX_XOR_AND, K_MIX_XOR_MIN16, K_OR_B32, K_SUB_U32, K_MIN_I32, K_MIN_F32, K_MUL_F32, K_MOV_B32, K_CMP_EQ_U64, K_CMP_EQ_U32_SGPR, K_NKINDS };
+            K_MIX_ALT, K_MIX_G4, K_MIX_G8, K_MIX_XOR_AND, K_MIX_XOR_MIN16, K_OR_B32, K_SUB_U32, K_MIN_I32, K_MIN_F32, K_MUL_F32, K_MOV_B32, K_CMP_EQ_U64, K_CMP_EQ_U32_SGPR,
+            K_BITOP3, K_BCNT, K_MIX_AND2_BCNT, K_MIX_BITOP2_BCNT, K_MIX_AND_RUN_BCNT_RUN, K_NKINDS };
 
 const char* kNames[K_NKINDS] = {
     "v_fma_f32", "v_add_u32", "v_xor_b32", "v_pk_min_u16", "v_xor_b32_dpp row_newbcast", "v_min3_u32", "v_pk_fma_f32",
@@ -32,7 +33,9 @@ const char* kNames[K_NKINDS] = {
     "v_min_u32", "v_and_b32", "v_xor_b32 v, s, v (SGPR operand)", "v_lshrrev_b32", "v_mov_b32_dpp row_newbcast", "v_and_or_b32", "v_bfi_b32",
     "join mix 2: v_xor_b32 (SGPR query) + v_pk_min_u16", "v_min_u16", "v_xor_b32_sdwa", "v_add_f32", "v_max_u32",
     "mix: v_xor_b32 (VGPR) / v_pk_min_u16 alternating", "mix: 4 x v_xor_b32 then 4 x v_pk_min_u16", "mix: 8 x v_xor_b32 then 8 x v_pk_min_u16",
-    "mix: v_xor_b32 / v_and_b32 alternating (both 2-cycle)", "mix: v_xor_b32 / v_min_u16 alternating (both 2-cycle)", "v_or_b32", "v_sub_u32", "v_min_i32", "v_min_f32", "v_mul_f32", "v_mov_b32", "v_cmp_eq_u64 -> SGPR pair", "v_cmp_eq_u32 -> SGPR pair"};
+    "mix: v_xor_b32 / v_and_b32 alternating (both 2-cycle)", "mix: v_xor_b32 / v_min_u16 alternating (both 2-cycle)", "v_or_b32", "v_sub_u32", "v_min_i32", "v_min_f32", "v_mul_f32", "v_mov_b32", "v_cmp_eq_u64 -> SGPR pair", "v_cmp_eq_u32 -> SGPR pair",
+    "v_bitop3_b32 (3-input boolean)", "v_bcnt_u32_b32 (accumulating)", "mix: 2 x v_and_b32 then v_bcnt_u32_b32", "mix: 2 x v_bitop3_b32 then v_bcnt_u32_b32",
+    "mix: runs of 16-32 v_and_b32 and of 8 v_bcnt_u32_b32 (3:1)"};
 
 template <int KIND>
 __global__ __launch_bounds__(256) void rate_kernel(uint32_t* __restrict__ out, unsigned long long* __restrict__ cyc, int iters) {
@@ -247,6 +250,42 @@ __global__ __launch_bounds__(256) void rate_kernel(uint32_t* __restrict__ out, u
 #define X(i) asm volatile("v_cmp_eq_u32 %0, %1, %2" : "=s"(sm[i & 3]) : "v"(a[i]), "v"(q[i]));
                 REP8(X)
 #undef X
+            } else if constexpr (KIND == K_BITOP3) {
+#define X(i) asm volatile("v_bitop3_b32 %0, %0, %1, %2 bitop3:0x80" : "+v"(a[i]) : "v"(q[i]), "v"(q[(i + 1) & 7]));
+                REP8(X)
+#undef X
+            } else if constexpr (KIND == K_BCNT) {
+#define X(i) asm volatile("v_bcnt_u32_b32 %0, %1, %0" : "+v"(a[i]) : "v"(q[i]));
+                REP8(X)
+#undef X
+            } else if constexpr (KIND == K_MIX_AND2_BCNT) {
+                // the bit-plane histogram's tree in plain VOP2 form: two node masks, one population count (9 instructions x ... = 8 per u: 3 groups of 2+1 minus one)
+#define X(i) asm volatile("v_and_b32 %0, %1, %2" : "=v"(t[i]) : "v"(q[i]), "v"(q[(i + 3) & 7])); \
+             asm volatile("v_and_b32 %0, %1, %2" : "=v"(t[i + 4]) : "v"(q[i]), "v"(q[(i + 5) & 7])); \
+             asm volatile("v_bcnt_u32_b32 %0, %1, %0" : "+v"(a[i]) : "v"(t[i]));
+                X(0) X(1)
+                asm volatile("v_and_b32 %0, %1, %2" : "=v"(t[2]) : "v"(q[2]), "v"(q[5]));
+                asm volatile("v_bcnt_u32_b32 %0, %1, %0" : "+v"(a[2]) : "v"(t[2]));
+#undef X
+            } else if constexpr (KIND == K_MIX_BITOP2_BCNT) {
+#define X(i) asm volatile("v_bitop3_b32 %0, %1, %2, %3 bitop3:0x80" : "=v"(t[i]) : "v"(q[i]), "v"(q[(i + 3) & 7]), "v"(q[(i + 1) & 7])); \
+             asm volatile("v_bitop3_b32 %0, %1, %2, %3 bitop3:0x40" : "=v"(t[i + 4]) : "v"(q[i]), "v"(q[(i + 5) & 7]), "v"(q[(i + 2) & 7])); \
+             asm volatile("v_bcnt_u32_b32 %0, %1, %0" : "+v"(a[i]) : "v"(t[i]));
+                X(0) X(1)
+                asm volatile("v_bitop3_b32 %0, %1, %2, %3 bitop3:0x80" : "=v"(t[2]) : "v"(q[2]), "v"(q[5]), "v"(q[6]));
+                asm volatile("v_bcnt_u32_b32 %0, %1, %0" : "+v"(a[2]) : "v"(t[2]));
+#undef X
+            } else if constexpr (KIND == K_MIX_AND_RUN_BCNT_RUN) {
+                // the same work with the plain instructions in a run of 16 and the counts in a run of 8 (three u-steps = one period)
+                if (u % 3 == 2) {
+#define Y(i) asm volatile("v_bcnt_u32_b32 %0, %1, %0" : "+v"(a[i]) : "v"(t[i]));
+                    REP8(Y)
+#undef Y
+                } else {
+#define X(i) asm volatile("v_and_b32 %0, %1, %2" : "=v"(t[i]) : "v"(q[i]), "v"(q[(i + 3) & 7]));
+                    REP8(X)
+#undef X
+                }
             } else if constexpr (KIND == K_PK_ADD_U16) {
 #define X(i) asm volatile("v_pk_add_u16 %0, %0, %1" : "+v"(a[i]) : "v"(q[i]));
                 REP8(X)
@@ -335,6 +374,18 @@ int main() {
     const double shader_hz = env ? atof(env) * 1e6 : 2.4e9;
     printf("shader clock assumed for the cycle conversion: %.0f MHz (SHADER_MHZ overrides); s_memtime tick rate %.1f MHz\n", shader_hz / 1e6, ticks_per_s / 1e6);
     const int iters = 4000;
+    if (getenv("BITPLANE_ONLY")) {                 // the instructions of the bit-plane histogram kernel (csrc/kernel_hllbs.cuh) and their controls
+        for (int W : {1, 2, 3, 4, 8}) {
+            run_kind<K_AND_B32>(d_out, d_cyc, W, iters, ticks_per_s, shader_hz);
+            run_kind<K_BITOP3>(d_out, d_cyc, W, iters, ticks_per_s, shader_hz);
+            run_kind<K_BCNT>(d_out, d_cyc, W, iters, ticks_per_s, shader_hz);
+            run_kind<K_BFI_B32>(d_out, d_cyc, W, iters, ticks_per_s, shader_hz);
+            run_kind<K_MIX_AND2_BCNT>(d_out, d_cyc, W, iters, ticks_per_s, shader_hz);
+            run_kind<K_MIX_BITOP2_BCNT>(d_out, d_cyc, W, iters, ticks_per_s, shader_hz);
+            run_kind<K_MIX_AND_RUN_BCNT_RUN>(d_out, d_cyc, W, iters, ticks_per_s, shader_hz);
+        }
+        return 0;
+    }
     for (int W : {1, 2, 4, 8}) {
         run_kind<K_FMA_F32>(d_out, d_cyc, W, iters, ticks_per_s, shader_hz);
         run_kind<K_ADD_U32>(d_out, d_cyc, W, iters, ticks_per_s, shader_hz);

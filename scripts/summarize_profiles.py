@@ -56,7 +56,7 @@ if perm:
 sq = [pmc("SQ_INSTS_VALU"), pmc("SQ_LDS_IDX_ACTIVE")]
 names = set(fetch) | set(write) | set(sq[0]) | set(sq[1])
 for k in sorted(names):
-    if not any(s in k for s in ("join", "smh_stream", "hll_union_hist_runs", "verify16", "ertl_select", "sig_build", "aux_fused", "csr_", "stream_interleave")):
+    if not any(s in k for s in ("join", "smh_stream", "hll_union_hist", "hll_bitslice", "verify16", "ertl_select", "sig_build", "aux_fused", "csr_", "stream_interleave")):
         continue
     e = {}
     if k in fetch:
@@ -89,7 +89,7 @@ if dom:
     t[key] = traffic
     t["source"] = "profiles/*_pmc_summary.json"
     tfile.write_text(json.dumps(t, indent=1))
-hk = [k for k in fetch if "hll_union_hist_runs" in k]
+hk = [k for k in fetch if "hll_union_hist_runs" in k or "hll_union_hist_bs" in k]
 sk = [k for k in fetch if "sig_build_kernel" in k or "cb_bounds_kernel" in k]       # one launch per pass
 if hk and sk:
     # stage 2a: bytes fetched from beyond L2 per PASS (all windows and chunk lanes of a pass together)
@@ -98,9 +98,9 @@ if hk and sk:
     tfile = out / "stage2_traffic.json"
     t = json.loads(tfile.read_text()) if tfile.exists() else {}
     t[key.split(":")[0]] = per_pass
-    t["source"] = "profiles/*_pmc_summary.json (FETCH_SIZE of hll_union_hist_runs_kernel, calibrated; bytes per pass)"
+    t["source"] = "profiles/*_pmc_summary.json (FETCH_SIZE of the stage-2a histogram kernel, calibrated; bytes per pass)"
     tfile.write_text(json.dumps(t, indent=1))
-    summary["stage2"] = {"kernel": "hll_union_hist_runs_kernel", "beyond_l2_bytes_per_pass": per_pass}
+    summary["stage2"] = {"kernel": short(hk[0]), "beyond_l2_bytes_per_pass": per_pass}
 (out / f"{tag}_pmc_summary.json").write_text(json.dumps(summary, indent=1))
 print(json.dumps(summary.get("stage1")), summary.get("fetch_calibration"))
 for k, e in summary["kernels"].items():

@@ -518,6 +518,62 @@ def test_building_blocks(oracle):
     assert flags.sum() > 0
 
 
+def test_bitplane_histograms(oracle):
+    """stage 2a's bit-plane kernel (csrc/kernel_hllbs.cuh) against numpy on register sets whose largest value selects each of its
+    instantiations (16 / 24 / 32 / 48 / 64 decoded values), including all-equal rows, an all-zero row and the value 63; and the
+    whole pass with the bit planes vs the byte-row LDS kernel ("hist_algo")"""
+    import torch
+    lib = pkg.hip_lib()
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(11)
+    for vmax in (3, 15, 16, 23, 24, 31, 32, 47, 51, 63):
+        n = 40
+        hll = rng.integers(0, vmax + 1, size=(n, 16384), dtype=np.uint8)
+        hll[0] = 0                                   # empty sketch
+        hll[1] = vmax                                # every register at the maximum
+        hll[2] = np.minimum(rng.geometric(0.5, 16384), vmax).astype(np.uint8)     # HLL-like
+        hll[3] = hll[2]
+        hll[4, ::7] = vmax
+        for g, cap_v in zip(range(5, 14), (3, 15, 17, 19, 20, 23, 24, 27, 31)):        # rows with smaller maxima: every per-pair tree size is taken
+            hll[g] = np.minimum(hll[g], min(cap_v, vmax))
+        pairs = np.stack([rng.integers(0, n, 300), rng.integers(0, n, 300)], axis=1).astype(np.int32)
+        pairs[:8] = [[0, 0], [0, 1], [1, 1], [2, 3], [3, 2], [0, 2], [4, 1], [4, 0]]
+        d_hll = torch.from_numpy(hll).to(dev)
+        d_pairs = torch.from_numpy(pairs).to(dev)
+        d_planes = torch.zeros((n, 6, 512), dtype=torch.int32, device=dev)
+        d_gmax = torch.zeros(n, dtype=torch.uint8, device=dev)
+        khi = C.c_int(0)
+        pkg._lib.check(lib.selhip_hll_bitslice(d_hll.data_ptr(), n, d_planes.data_ptr(), d_gmax.data_ptr(), C.byref(khi), None))
+        assert khi.value == vmax + 1
+        assert np.array_equal(d_gmax.cpu().numpy(), hll.max(axis=1))
+        planes = d_planes.cpu().numpy().view(np.uint32)
+        # every register lands on exactly one bit of every plane: plane b's population = number of registers with bit b set
+        for g in (0, 1, 2, 4, n - 1):
+            for bit in range(6):
+                assert int(np.unpackbits(planes[g, bit].view(np.uint8)).sum()) == int(((hll[g] >> bit) & 1).sum()), (vmax, g, bit)
+        d_counts = torch.full((300, 64), -1, dtype=torch.int32, device=dev)
+        pkg._lib.check(lib.selhip_hll_union_hist_planes(d_planes.data_ptr(), d_gmax.data_ptr(), khi.value, d_pairs.data_ptr(), 300, d_counts.data_ptr(), None))
+        counts = d_counts.cpu().numpy().view(np.uint32)
+        for j in range(300):
+            want = np.bincount(np.maximum(hll[pairs[j, 0]], hll[pairs[j, 1]]), minlength=64).astype(np.uint32)
+            assert np.array_equal(counts[j], want), (vmax, j, pairs[j])
+            assert np.array_equal(want, oracle.union_hist(hll[pairs[j, 0]], hll[pairs[j, 1]]))
+    cfg = make_golden.GOLDEN_SYNTH["synth_spread_n600_m64"]
+    hll, aux, cards, _, _ = sorted_set(cfg, oracle)
+    r, b = pkg.banding(cfg.m, 0.5)
+    want, st = oracle.select(hll, aux, cards, 0.5, r, b)
+    with Selector(0) as sel:
+        for algo in (0, 1, -1):
+            sel.set_param("hist_algo", algo)
+            sel.upload(hll, aux, cards)
+            for run, blocks, label in ((1, 8, 0), (3, 64, 1), (0, 2048, -1)):
+                sel.set_param("hist_run", run); sel.set_param("hist_bs_blocks", blocks); sel.set_param("group_label", label)
+                assert_same_pairs(sel.run(0.5, MODE_CB_SMH, r, b), want)
+                assert sel.stats()["survivors"] == st["survivors"]
+        with pytest.raises(pkg.SelhipError):
+            sel.set_param("hist_algo", 2)
+
+
 def test_estimator_rare_branches(oracle):
     """hll.h:642 (all registers saturated -> +inf), hll.h:659 log1p start point (gprev > 1.5*a: registers
     near saturation), empty sketch, single non-empty register -- forced inputs (never hit by random data)"""
