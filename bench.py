@@ -22,9 +22,11 @@ full replica of the sketches.
 before anything in this process has touched the GPU, and exits with the child's code.
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with the extra objects
-  roofline          the binding resource of the dominant kernel (vector-instruction issue for the signature join), frac <= 1;
+  roofline          the binding resource of the kernel that is the LONGEST of the step by measured duration (the all-pairs signature
+                    join, or stage 2a's union histograms): vector-instruction issue, `frac` against the mix-weighted peak plus the
+                    same rate against the guide's raw issue rate and the measured mixed rate, the model count beside PMC's SQ_INSTS_VALU;
+  stage2_roofline / stage1_roofline   the other stage's roofline; roofline_choice says which kernel was chosen and why;
   hbm_algorithmic   SURVEY.md 8(d)'s nominal 8*m bytes per pair-comparison against the HBM peak (NOT a bound of this design);
-  stage2_roofline   LDS issue of the union-histogram kernel;
   stream_kernel     the literal north_star kernel (query tile in LDS, candidates streamed from HBM) on the same inputs;
   harder_workload   the same configuration with 25 % degenerate genomes (1.4 % of all pairs pass a band);
   cpu_baseline      the oracle (OpenMP port of selection.cpp's loop) on a bounded sample, all cores; cpu_baseline_8t: 8 threads.
@@ -51,6 +53,9 @@ SHADER_HZ = 2.4e9              # profiles/r02_valu_rate.txt: s_memtime tick rate
 # profiles/r02_valu_rate.txt (scripts/microbench/valu_rate.hip), cycles per wave64 instruction per SIMD at >= 4 waves/SIMD:
 CYC_VALU_PLAIN = 2.07          # VGPR-only VOP2 (v_xor_b32, v_and_b32, v_add_u32, v_min_u16, v_fma_f32 ...) -- two waves co-issue
 CYC_VALU_FULL = 4.07           # anything with DPP / SDWA / an SGPR operand / three sources (VOP3) / packed math (VOP3P)
+CYC_VALU_RAW = 2.0             # MI355X_MICROARCH.md: a wave64 VALU instruction issues in 2 cycles per SIMD (4 for one wave alone)
+CYC_MIX_MEASURED = 3.85        # profiles/r02_valu_rate.txt, rows "mix: v_xor_b32 (VGPR) / v_pk_min_u16": 3.76-3.95 cycles per instruction
+CYC_BITOP3 = 2.2               # profiles/r03_bitplane_rate.txt: v_bitop3_b32 2.17-2.27 cycles (it pairs like a VGPR-only VOP2); v_bcnt_u32_b32 4.05
 CYC_DS_2DWORD = 4.0            # MI355X_MICROARCH.md LDS table: a DS op moving 2 dwords per lane (ds_add_u32, ds_write_b32) = 4 cycles/CU
 IL_BLOCK = 128                 # rows per interleave block of the multi-GPU partition
 
@@ -252,10 +257,22 @@ def main():
             dist.barrier()
             torch.cuda.synchronize(dev)
 
+    # warm-up with every kernel timed: decides which kernel is the longest of the step -- the one whose HIP events stay on inside the
+    # timed region (timing level 2: an event pair costs ~10 us of stream time, so only one kernel keeps them there; the other
+    # kernels' figures are collected in extra passes after the timed region)
+    sel.timing(1)
     for _ in range(max(1, args.warmup)):
         step()
-    # HIP events over the timed region on the dominant stage-1 kernel only (timing level 2): an event pair costs ~10 us of
-    # stream time, so the other kernels' figures are collected in extra passes after the timed region
+    torch.cuda.synchronize(dev)
+    used_sig = sel.kernel_ms("join") > 0
+    dom_key = "join" if used_sig else "stage1"
+    timed_hist = 1 if sel.kernel_ms("hist") > sel.kernel_ms(dom_key) else 0
+    sel.set_param("timed_kernel", timed_hist)
+    khi = sel.get_param("hll_khi")
+    info = {"bitplanes": bool(sel.get_param("hist_bitplanes")), "khi": khi, "planes": 4 if khi <= 16 else (5 if khi <= 32 else 6),
+            "label": bool(sel.get_param("label_order"))}
+    info["layout"] = (f"p=14 registers as 6 bit planes of 512 dwords per genome (12 KiB; {info['planes']} planes non-zero in this set), written once at attach"
+                      if info["bitplanes"] else "p=14 registers as bytes (16 KiB per genome)")
     sel.timing(2)
     sync_all()
     t0 = time.perf_counter()
@@ -264,16 +281,16 @@ def main():
     sync_all()
     dt = time.perf_counter() - t0
     st = sel.stats()
-    used_sig = sel.kernel_ms("join") > 0
-    dom_key = "join" if used_sig else "stage1"
-    dom_pass_ms = sel.kernel_ms(dom_key)                         # all launches of one pass (a pipelined pass: one per row chunk)
-    dom_launches = max(1.0, sel.kernel_launches(dom_key))
-    dom_span_ms = sel.kernel_ms("join_span") if used_sig else -1.0   # first start -> last end of the pass's join launches (chunk lanes overlap them)
+    timed_key = "hist" if timed_hist else dom_key
+    dom_pass_ms = sel.kernel_ms(timed_key)                       # all launches of one pass (a pipelined pass: one per row chunk)
+    dom_launches = max(1.0, sel.kernel_launches(timed_key))
+    dom_span_ms = sel.kernel_ms("join_span") if (used_sig and not timed_hist) else -1.0   # first start -> last end of the pass's join launches (chunk lanes overlap them)
     sel.timing(1)                                                # outside the timed region: every kernel scope, a few passes
     for _ in range(5):
         step()
     torch.cuda.synchronize(dev)
     detail_ms = {k: sel.kernel_ms(k) for k in ("prep", "sigbuild", "join", "verify", "stage1", "aux", "group", "hist", "select", "total")}
+    stage1_launches = max(1.0, sel.kernel_launches(dom_key))
     sel.timing(0)
 
     t_max = torch.tensor([dt], dtype=torch.float64, device=cdev)
@@ -304,29 +321,14 @@ def main():
     out = None
     if rank == 0:
         pairs_rank0 = st["evaluated"]
-        launches = dom_launches
-        dom_ms = dom_pass_ms / launches                          # average launch duration, measured inside the timed region
+        launches = stage1_launches
+        dom_ms = dom_pass_ms / dom_launches                      # average launch duration of the timed kernel, measured inside the timed region
         alg_bytes = pairs_rank0 * 8 * cfg.m / launches           # 8*m bytes per pair-comparison, per launch
-        if used_sig:
-            dom_name = (f"sigl_join_kernel<{n_bands // 2}> (query tile in LDS)" if join_q else f"sig16_join_kernel<{n_bands // 2}> (DPP broadcast)") \
-                if args.algo != "hashjoin" else "sort-based join"
-        else:
-            dom_name = "smh_stream_kernel"
-        traffic, traffic_src = None, None
-        tfile = ROOT / "profiles" / "stage1_traffic.json"
-        if tfile.exists():
-            try:
-                tj = json.loads(tfile.read_text())
-                traffic = tj.get(f"{args.workload}:{'sig' if used_sig else 'stream'}")
-                traffic = traffic / launches if traffic else traffic        # stored per step
-                traffic_src = tj.get("source", "profiles/stage1_traffic.json") + " (rocprofv3 --pmc pass of this command on an earlier run; NOT measured by this run)"
-            except Exception:
-                traffic = None
-        hist_ms = detail_ms["hist"]
-        surv0 = st["survivors"]
+        wkey = args.workload + ("hard" if args.hard else "")
         kernels = {k: v for k, v in detail_ms.items() if v > 0}
-        kernels[dom_key + "_in_timed_region"] = dom_pass_ms
-        achieved_hbm = alg_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else None
+        kernels[timed_key + "_in_timed_region"] = dom_pass_ms
+        stage1_ms = detail_ms["join"] if used_sig else detail_ms["stage1"]
+        achieved_hbm = alg_bytes / (stage1_ms / launches * 1e-3) / 1e9 if stage1_ms > 0 else None
         out = {
             "metric": "sketch pair-comparisons/sec (N genomes x m buckets)",
             "value": value, "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -338,83 +340,45 @@ def main():
                        "algo": "hashjoin (pairs are NOT compared one by one: equivalent pairs/s)" if args.algo == "hashjoin" else ("sig" if used_sig else "stream"),
                        "criterion": "hll_a+smh_a" if two_stage else "smh_a",
                        "pairs_per_step": pairs_per_step, "selected_pairs": int(totals[2].item()),
-                       "stage1_survivors": int(totals[1].item()), "n_ranks_seen": n_ranks_seen},
+                       "stage1_survivors": int(totals[1].item()), "n_ranks_seen": n_ranks_seen,
+                       "hll_layout": info["layout"], "stage2_grouping": "label order" if info["label"] else "query-row order"},
             "bucket_pair_comparisons_per_s_nominal": value * cfg.m,
             "kernel_ms": kernels,
         }
-        if used_sig and args.algo != "hashjoin" and dom_ms > 0:
+        # ---- rooflines: one per stage; `roofline` = that of the kernel that is the longest of the step (durations of the passes
+        # with every kernel timed, outside the timed region; the one chosen for the timed region's events is stated)
+        r1 = None
+        if used_sig and args.algo != "hashjoin" and stage1_ms > 0:
             out["bucket_pair_comparisons_note"] = ("nominal = pairs/s x m: the signature join decides every pair from n_bands 16-bit band "
                                                    "signatures, it does not execute m bucket compares per pair (the stream kernel's figure in "
                                                    "`stream_kernel` is the executed one)")
-            row_waves = pairs_rank0 / 64.0                     # one query row against one group of 64 candidates
-            mdl = join_issue_model(n_bands, join_q)
-            n_instr = mdl["plain"] + mdl["full"]
-            cyc_mix = (mdl["plain"] * CYC_VALU_PLAIN + mdl["full"] * CYC_VALU_FULL) / n_instr
-            peak = N_SIMD * SHADER_HZ / cyc_mix
-            achieved = row_waves * n_instr / (dom_pass_ms * 1e-3)
-            out["roofline"] = {
-                "bound": "valu_issue", "kernel": dom_name + " (stage 1, all-pairs)", "achieved": achieved / 1e9, "peak": peak / 1e9,
-                "unit": "G wave-instr/s", "frac": achieved / peak, "traffic": traffic, "traffic_source": traffic_src,
-                "avg_launch_ms": dom_ms, "launches_per_step": launches,
-                **({"concurrent_launches": {
-                    "span_ms": dom_span_ms, "frac_of_chip_while_running": row_waves * n_instr / (dom_span_ms * 1e-3) / peak,
-                    "note": "this pass is cut into row chunks whose chains run on two streams (selhip_ctx_set_pipeline, automatic from 1e9 pairs): "
-                            "the join launches run side by side, each on about half of the chip, so `frac` (work of a launch / its own duration / "
-                            "whole-chip peak, the same durations rocprofv3 reports) is about half of what the chip delivers while they run; "
-                            "span_ms = first start to last end of the pass's join launches, frac_of_chip_while_running = all their work / span / peak "
-                            "(the other chunk's verification / stage-2 kernels run inside that span too).  --pipeline 0 gives the single-launch figure"}}
-                   if launches > 1.5 and dom_span_ms > 0 else {}),
-                "instr_per_row_wave": mdl, "cycles_per_instr_at_peak": cyc_mix,
-                "peak_derivation": f"{N_SIMD} SIMDs x {SHADER_HZ / 1e9} GHz / mix-weighted issue cost; profiles/r02_valu_rate.txt: "
-                                   f"VGPR-only VOP2 {CYC_VALU_PLAIN} cycles (two waves co-issue), every DPP/SDWA/SGPR-operand/VOP3/packed instruction "
-                                   f"{CYC_VALU_FULL} cycles; the same file's 'mix: v_xor_b32 / v_pk_min_u16' rows (3.75-3.93 cycles per instruction) show "
-                                   "that a plain instruction only pairs with another plain one, so this peak is not reachable with a packed min in the loop",
-                "note": "achieved = model count of VALU wave-instructions (ISA, csrc/kernel_sigjoin.cuh) / join time inside the timed region; "
-                        "PMC SQ_INSTS_VALU of the same kernel: profiles/"}
+            in_region = dom_key == "join" and timed_hist == 0
+            r1 = join_roofline(pairs_rank0, n_bands, join_q, dom_pass_ms if in_region else detail_ms["join"], launches, dom_span_ms if in_region else -1.0,
+                               wkey, "HIP events inside the timed region" if in_region else "HIP events of 5 extra passes after the timed region")
+        elif not used_sig and cfg.m % 128 == 0 and (n_rows & (n_rows - 1)) == 0 and stage1_ms > 0:
+            r1 = stream_issue_roofline(cfg.m, n_rows, pairs_rank0 / launches, stage1_ms / launches)
+            if r1:
+                r1.update({"avg_launch_ms": stage1_ms / launches, "launches_per_step": launches, "traffic": traffic_of("stage1", f"{args.workload}:stream")[0]})
+        r2 = None
+        if detail_ms["hist"] > 0:
+            h_ms = dom_pass_ms if timed_hist else detail_ms["hist"]
+            r2 = hist_roofline(st["survivors"], h_ms, max(1.0, sel.kernel_launches("hist")), info, n_genomes, wkey,
+                               "HIP events inside the timed region" if timed_hist else "HIP events of 5 extra passes after the timed region")
+        hist_longest = r2 is not None and detail_ms["hist"] > stage1_ms
+        if hist_longest:
+            out["roofline"], out["stage1_roofline"] = r2, r1
         else:
-            out["roofline"] = {"bound": "salu_issue" if not used_sig else "n/a", "kernel": dom_name, "avg_launch_ms": dom_ms,
-                               "launches_per_step": launches, "traffic": traffic, "traffic_source": traffic_src,
-                               "achieved": None, "peak": None, "unit": "G instr/s", "frac": None}
-            if not used_sig and cfg.m % 128 == 0 and (n_rows & (n_rows - 1)) == 0 and dom_ms > 0:
-                try:                                             # the literal stream kernel as the main algorithm: its issue roofline
-                    r_ = stream_issue_roofline(cfg.m, n_rows, pairs_rank0 / launches, dom_ms)
-                    if r_:
-                        out["roofline"].update(r_)
-                except Exception:
-                    pass
+            out["roofline"] = r1 or {"bound": "n/a", "kernel": "sort-based join" if args.algo == "hashjoin" else "stage 1", "avg_launch_ms": dom_ms,
+                                     "launches_per_step": launches, "achieved": None, "peak": None, "unit": "G instr/s", "frac": None, "traffic": None}
+            out["stage2_roofline"] = r2
+        out["roofline_choice"] = {"longest_kernel": "stage 2a (union histograms)" if hist_longest else "stage 1",
+                                  "stage1_ms_per_step": stage1_ms, "stage2a_ms_per_step": detail_ms["hist"],
+                                  "timed_region_events_on": "hist" if timed_hist else dom_key}
         out["hbm_algorithmic"] = {"bytes_per_pair": 8 * cfg.m, "achieved_GBs": achieved_hbm, "peak_GBs": HBM_PEAK_GBS,
                                   "ratio": (achieved_hbm / HBM_PEAK_GBS) if achieved_hbm else None,
                                   "note": "SURVEY.md 8(d) nominal: one candidate sketch streamed per pair-comparison.  NOT a bound of this design: "
                                           "both stage-1 kernels reuse every byte they load against a tile of queries, so the ratio exceeds 1; "
-                                          "measured HBM traffic per launch is `roofline.traffic`"}
-        if hist_ms > 0:
-            # stage 2a has two candidate bounds: the LDS (one ds_add_u32 per 64 register pairs) and the fabric behind L2 (HLL rows that are
-            # no longer in the XCD's 4 MiB L2 when their next pair comes up); both fractions are reported, the larger one binds
-            ds_rate = surv0 * 256 / (hist_ms * 1e-3)
-            ds_peak = 256 * SHADER_HZ / CYC_DS_2DWORD
-            fetch, fetch_src = None, None
-            t2 = ROOT / "profiles" / "stage2_traffic.json"
-            if t2.exists():
-                try:
-                    tj = json.loads(t2.read_text())
-                    fetch = tj.get(args.workload + ("hard" if args.hard else ""))      # bytes per pass
-                    if fetch:
-                        fetch_src = tj.get("source", "") + " -- an earlier rocprofv3 --pmc run of this command, NOT measured by this run"
-                except Exception:
-                    fetch = None
-            fabric_peak = FABRIC_GATHER_GBS if n_genomes * 16384 <= (256 << 20) else HBM_MEASURED_GBS
-            out["stage2_roofline"] = {"kernel": "hll_union_hist_runs_kernel", "ms_per_step": hist_ms,
-                                      "lds_issue": {"achieved": ds_rate / 1e9, "peak": ds_peak / 1e9, "unit": "G ds_add_u32 wave-instr/s", "frac": ds_rate / ds_peak,
-                                                    "note": "one conflict-free ds_add_u32 per 64 register pairs, 256 per pair of the final list; peak = 256 CUs x one DS op of "
-                                                            f"2 dwords per {CYC_DS_2DWORD} cycles (MI355X_MICROARCH.md LDS table; profiles/r02_lds_rate.txt measures 4.4-5.1)"},
-                                      "beyond_l2_fetch": {"bytes_per_step": fetch, "achieved_GBs": (fetch / (hist_ms * 1e-3) / 1e9) if fetch else None,
-                                                          "peak_GBs": fabric_peak, "frac": (fetch / (hist_ms * 1e-3) / 1e9 / fabric_peak) if fetch else None,
-                                                          "source": fetch_src,
-                                                          "note": "peak = what MI355X_MICROARCH.md measures for gathered whole rows: 7 400 GB/s from the Infinity Cache "
-                                                                  "(tables up to ~150 MB), 6 000-6 300 GB/s from HBM; minimum traffic = every HLL row once"},
-                                      "row_bytes_per_s": surv0 * 32768 / (hist_ms * 1e-3),
-                                      "grouping": "automatic: label order (a row's smallest partner first) when the HLL rows exceed 192 MiB and the pass has "
-                                                  ">= 4e8 pairs, else query-row order"}
+                                          "measured HBM traffic per launch is `traffic` of the stage-1 roofline"}
         if n_degenerate:
             out["config"]["degenerate_genomes"] = n_degenerate
 
@@ -466,11 +430,17 @@ def main():
             for _ in range(3):
                 s3.run(cfg.tau, mode, n_rows, n_bands, fetch=False)
             hk = {k: s3.kernel_ms(k) for k in ("sigbuild", "join", "verify", "group", "hist", "select")}
+            h_launches = {k: max(1.0, s3.kernel_launches(k)) for k in ("join", "hist")}
             s3.timing(0)
+        clock_h = "HIP events of 3 passes with every kernel timed"
+        hr2 = hist_roofline(hs["survivors"], hk["hist"], h_launches["hist"], info, n_genomes, args.workload + "hard", clock_h) if hk["hist"] > 0 else None
+        hr1 = join_roofline(hs["evaluated"], n_bands, join_q, hk["join"], h_launches["join"], -1.0, args.workload + "hard", clock_h) if hk["join"] > 0 else None
         out["harder_workload"] = {"workload": f"{cfg.name} with {n_deg} of {n_genomes} genomes degenerate (buckets mod 2): pairs among them pass a band by chance",
                                   "value": hs["evaluated"] / dth, "unit": "pairs/s", "ms_per_step": dth * 1e3,
                                   "stage1_survivors": hs["survivors"], "survivor_fraction": hs["survivors"] / max(1, hs["evaluated"]),
-                                  "selected_pairs": hs["selected"], "kernel_ms": {k: v for k, v in hk.items() if v > 0}}
+                                  "selected_pairs": hs["selected"], "kernel_ms": {k: v for k, v in hk.items() if v > 0},
+                                  "roofline": hr2 if hk["hist"] >= hk["join"] else hr1,
+                                  "other_stage_roofline": hr1 if hk["hist"] >= hk["join"] else hr2}
         del aux_h
 
     # ---- CPU baseline: the oracle (OpenMP port of selection.cpp:270-291 / time_smh.cpp:229-257) on a bounded sample
@@ -557,6 +527,112 @@ def main():
     sel.close()
     if dist_on:
         dist.destroy_process_group()
+
+
+def _json(path):
+    try:
+        return json.loads(path.read_text())
+    except Exception:
+        return {}
+
+
+def traffic_of(stage, key):
+    """bytes per step from beyond L2 recorded by an EARLIER rocprofv3 --pmc run of the same command (scripts/gpu_profile.sh +
+    scripts/summarize_profiles.py write profiles/stage1_traffic.json / stage2_traffic.json); PMC needs the profiler, so an
+    ordinary run cannot measure it"""
+    tj = _json(ROOT / "profiles" / f"{stage}_traffic.json")
+    v = tj.get(key)
+    return (v, (tj.get("source", "profiles/") + " -- an earlier rocprofv3 --pmc run of this command, NOT measured by this run") if v else None)
+
+
+def pmc_valu(wkey, kernel):
+    """SQ_INSTS_VALU per launch of `kernel` in the committed PMC summary of this workload (profiles/pmc_counts.json)"""
+    return _json(ROOT / "profiles" / "pmc_counts.json").get(wkey, {}).get(kernel, {}).get("SQ_INSTS_VALU")
+
+
+def issue_fracs(wave_instr_per_s, cyc_model):
+    """the same achieved rate against three denominators: the model's mix-weighted cost, the guide's raw wave64 issue rate (2 cycles
+    per instruction per SIMD) and, for a plain/full mix, the pairing rate measured for such a mix"""
+    return {"frac": wave_instr_per_s / (N_SIMD * SHADER_HZ / cyc_model),
+            "frac_vs_raw_issue_rate": wave_instr_per_s / (N_SIMD * SHADER_HZ / CYC_VALU_RAW),
+            "frac_vs_measured_mix_rate": wave_instr_per_s / (N_SIMD * SHADER_HZ / CYC_MIX_MEASURED)}
+
+
+def join_roofline(pairs, n_bands, join_q, pass_ms, launches, span_ms, wkey, clock):
+    """VALU issue of the all-pairs signature join: model instruction count (ISA) over the measured duration"""
+    row_waves = pairs / 64.0                                   # one query row against one group of 64 candidates
+    mdl = join_issue_model(n_bands, join_q)
+    n_instr = mdl["plain"] + mdl["full"]
+    cyc_mix = (mdl["plain"] * CYC_VALU_PLAIN + mdl["full"] * CYC_VALU_FULL) / n_instr
+    peak = N_SIMD * SHADER_HZ / cyc_mix
+    achieved = row_waves * n_instr / (pass_ms * 1e-3)
+    traffic, traffic_src = traffic_of("stage1", f"{wkey}:sig")
+    pmc = pmc_valu(wkey, "join")
+    r = {"bound": "valu_issue", "kernel": (f"sigl_join_kernel<{n_bands // 2}> (query tile in LDS)" if join_q else f"sig16_join_kernel<{n_bands // 2}> (DPP broadcast)") + " (stage 1, all-pairs)",
+         "achieved": achieved / 1e9, "peak": peak / 1e9, "unit": "G wave-instr/s", **issue_fracs(achieved, cyc_mix),
+         "traffic": traffic / launches if traffic else None, "traffic_source": traffic_src,
+         "avg_launch_ms": pass_ms / launches, "launches_per_step": launches, "clock": clock,
+         "instr_per_row_wave": mdl, "cycles_per_instr_at_peak": cyc_mix,
+         "model_vs_pmc": {"model_wave_instr_per_step": row_waves * n_instr, "pmc_SQ_INSTS_VALU_per_step": pmc,
+                          "pmc_over_model": (pmc / (row_waves * n_instr)) if pmc else None, "source": "profiles/pmc_counts.json"},
+         "denominators": f"frac: {N_SIMD} SIMDs x {SHADER_HZ / 1e9} GHz / mix-weighted cost ({mdl['plain']} VGPR-only VOP2 at {CYC_VALU_PLAIN} cycles + {mdl['full']} "
+                         f"VOP3/VOP3P/DPP/SDWA instructions at {CYC_VALU_FULL}, profiles/r02_valu_rate.txt) -- not reachable with a packed min in the loop, because a "
+                         f"plain instruction only pairs with another plain one; frac_vs_raw_issue_rate: the guide's {CYC_VALU_RAW} cycles per wave64 instruction; "
+                         f"frac_vs_measured_mix_rate: {CYC_MIX_MEASURED} cycles, the measured rate of the alternating xor / packed-min mix (3.76-3.95)"}
+    if launches > 1.5 and span_ms > 0:
+        r["concurrent_launches"] = {"span_ms": span_ms, "frac_of_chip_while_running": row_waves * n_instr / (span_ms * 1e-3) / peak,
+                                    "note": "this pass is cut into row chunks whose chains run on two streams (selhip_ctx_set_pipeline, automatic from 1e9 pairs): the join "
+                                            "launches run side by side, each on about half of the chip, so `frac` (work of a launch / its own duration / whole-chip peak) is "
+                                            "about half of what the chip delivers while they run; span_ms = first start to last end of the pass's join launches.  --pipeline 0 "
+                                            "gives the single-launch figure"}
+    return r
+
+
+def hist_model_bitplanes(khi):
+    """VALU wave-instructions per pair of hll_union_hist_bs_kernel on its always-taken walk (csrc/kernel_hllbs.cuh): per column 2 NB
+    booleans for the bit-serial maximum + 4 per group of four values, one accumulating population count per decoded value; then packing,
+    the transposing reduction and the store.  Pairs with a register above 23 (15 with four planes) take further walks, not counted."""
+    nb = 4 if khi <= 16 else (5 if khi <= 32 else 6)
+    groups = 4 if nb == 4 else 6
+    return {"planes": nb, "values_decoded": 4 * groups, "boolean": 8 * (2 * nb + 4 * groups + (2 if nb == 6 else 0)),
+            "bcnt": 8 * 4 * groups, "tail_full_cost": 5 * groups + 35 + 8}
+
+
+def hist_roofline(survivors, hist_ms, launches, info, n_genomes, wkey, clock):
+    """stage 2a.  Bit planes: VALU issue (model count / time) and the fetches from beyond L2; byte rows: LDS issue and the same fetches"""
+    fetch, fetch_src = traffic_of("stage2", wkey)
+    row_bytes = (info["planes"] * 2048) if info["bitplanes"] else 16384
+    table = n_genomes * row_bytes
+    fabric_peak = FABRIC_GATHER_GBS if table <= (256 << 20) else HBM_MEASURED_GBS
+    fb = {"bytes_per_step": fetch, "achieved_GBs": (fetch / (hist_ms * 1e-3) / 1e9) if fetch else None, "peak_GBs": fabric_peak,
+          "frac": (fetch / (hist_ms * 1e-3) / 1e9 / fabric_peak) if fetch else None, "source": fetch_src,
+          "minimum_bytes": table, "bytes_per_pair_no_reuse": row_bytes,
+          "note": "peak = what MI355X_MICROARCH.md measures for gathered whole rows: 7 400 GB/s from the Infinity Cache (tables up to ~150 MB), "
+                  "6 000-6 300 GB/s from HBM; minimum = every row of the table once"}
+    if info["bitplanes"]:
+        m = hist_model_bitplanes(info["khi"])
+        n_instr = m["boolean"] + m["bcnt"] + m["tail_full_cost"]
+        cyc = (m["boolean"] * CYC_BITOP3 + (m["bcnt"] + m["tail_full_cost"]) * CYC_VALU_FULL) / n_instr
+        achieved = survivors * n_instr / (hist_ms * 1e-3)
+        pmc = pmc_valu(wkey, "hist")
+        return {"bound": "valu_issue", "kernel": f"hll_union_hist_bs_kernel<{m['planes']}> (stage 2a: union histograms on bit planes)",
+                "achieved": achieved / 1e9, "peak": N_SIMD * SHADER_HZ / cyc / 1e9, "unit": "G wave-instr/s", **issue_fracs(achieved, cyc),
+                "traffic": fetch / launches if fetch else None, "traffic_source": fetch_src,
+                "avg_launch_ms": hist_ms / launches, "launches_per_step": launches, "clock": clock, "pairs_per_step": survivors,
+                "instr_per_pair": m, "cycles_per_instr_at_peak": cyc,
+                "model_vs_pmc": {"model_wave_instr_per_step": survivors * n_instr, "pmc_SQ_INSTS_VALU_per_step": pmc,
+                                 "pmc_over_model": (pmc / (survivors * n_instr)) if pmc else None, "source": "profiles/pmc_counts.json"},
+                "beyond_l2_fetch": fb,
+                "denominators": f"frac: v_bitop3_b32 / v_and_b32 at {CYC_BITOP3} cycles, v_bcnt_u32_b32 and the DPP / permlane / VOP3 tail at {CYC_VALU_FULL} "
+                                f"(profiles/r03_bitplane_rate.txt); frac_vs_raw_issue_rate: {CYC_VALU_RAW} cycles for every instruction; frac_vs_measured_mix_rate: "
+                                f"{CYC_MIX_MEASURED} cycles (the join's mix -- kept for comparison with the stage-1 line)"}
+    ds_rate = survivors * 256 / (hist_ms * 1e-3)
+    ds_peak = 256 * SHADER_HZ / CYC_DS_2DWORD
+    return {"bound": "lds_issue", "kernel": "hll_union_hist_runs_kernel (stage 2a: byte rows, lane-private LDS histogram)", "achieved": ds_rate / 1e9, "peak": ds_peak / 1e9,
+            "unit": "G ds_add_u32 wave-instr/s", "frac": ds_rate / ds_peak, "traffic": fetch / launches if fetch else None, "traffic_source": fetch_src,
+            "avg_launch_ms": hist_ms / launches, "launches_per_step": launches, "clock": clock, "pairs_per_step": survivors, "beyond_l2_fetch": fb,
+            "note": f"one conflict-free ds_add_u32 per 64 register pairs, 256 per pair; peak = 256 CUs x one DS op of 2 dwords per {CYC_DS_2DWORD} cycles "
+                    "(MI355X_MICROARCH.md LDS table; profiles/r02_lds_rate.txt measures 4.4-5.1)"}
 
 
 def stream_issue_roofline(m, n_rows, pairs, launch_ms):

@@ -62,6 +62,7 @@ HIP_SYMBOLS = {
     "selhip_ctx_set_pipeline": (_i, [_vp, _i]),
     "selhip_ctx_set_stage2_grouping": (_i, [_vp, _i]),
     "selhip_ctx_set_param": (_i, [_vp, _cp, _i]),
+    "selhip_ctx_get_param": (_i, [_vp, _cp, _vp]),
     "selhip_ctx_set_row_interleave": (_i, [_vp, _i, _i, _i]),
     "selhip_ctx_upload": (_i, [_vp, _vp, _vp, _vp, _i64, _i, _i]),
     "selhip_ctx_attach": (_i, [_vp, _vp, _vp, _vp, _i64, _i, _i]),

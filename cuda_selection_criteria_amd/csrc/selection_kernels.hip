@@ -192,6 +192,7 @@ struct selhip_ctx {
 
     int timing = 0;                     // 0 off, 1 every kernel scope, 2 dominant stage-1 kernel only
     int dominant_timer = T_STAGE1;
+    int timed_kernel = 0;               // timing level 2 keeps the events of: 0 = the stage-1 kernel (join / stream), 1 = stage 2a ("timed_kernel")
     long timed_passes = 0;
     int last_attempts = 0;              // enqueues the last finished run needed (1 = nothing overflowed)
     KernelTimer timers[T_COUNT];
@@ -803,7 +804,7 @@ int enqueue_pass(selhip_ctx* c) {
         const bool smh = crit == SELHIP_CRIT_SMH_A || crit == SELHIP_CRIT_HLL_A_SMH_A;
         const bool sig = smh && (c->algo == SELHIP_ALGO_HASHJOIN ||
                                  ((c->algo == SELHIP_ALGO_SIG || c->algo == SELHIP_ALGO_AUTO) && sig_supported(c->m, c->n_rows, c->n_bands)));
-        c->dominant_timer = sig ? T_JOIN : T_STAGE1;
+        c->dominant_timer = c->timed_kernel == 1 ? T_HIST : (sig ? T_JOIN : T_STAGE1);
         if (c->timing) c->timed_passes += 1;
     }
     TimerScope total(c, T_TOTAL);
@@ -1145,6 +1146,11 @@ int selhip_ctx_set_param(selhip_ctx* c, const char* name, int value) {
         c->hist_pad = value;
         return SELHIP_OK;
     }
+    if (!std::strcmp(name, "timed_kernel")) {
+        if (value < 0 || value > 1) { set_err(&c->err, "timed_kernel must be 0 (stage-1 kernel) or 1 (stage 2a)"); return SELHIP_E_BADARG; }
+        c->timed_kernel = value;
+        return SELHIP_OK;
+    }
     if (!std::strcmp(name, "hist_algo")) {
         // takes effect at the next selhip_ctx_upload / _attach (the bit planes are written there)
         if (value < -1 || value > 1) { set_err(&c->err, "hist_algo must be -1 (automatic), 0 (byte rows, LDS histogram) or 1 (bit planes)"); return SELHIP_E_BADARG; }
@@ -1163,6 +1169,16 @@ int selhip_ctx_set_param(selhip_ctx* c, const char* name, int value) {
         return SELHIP_OK;
     }
     set_err(&c->err, "unknown parameter '%s'", name);
+    return SELHIP_E_BADARG;
+}
+
+int selhip_ctx_get_param(const selhip_ctx* c, const char* name, int* value) {
+    if (!c || !name || !value) return SELHIP_E_BADARG;
+    if (!std::strcmp(name, "hll_khi"))          { *value = c->hll_khi; return SELHIP_OK; }             // largest p = 14 register value + 1 (0: no bit planes)
+    if (!std::strcmp(name, "hist_bitplanes"))   { *value = use_bitslices(c) ? 1 : 0; return SELHIP_OK; }
+    if (!std::strcmp(name, "label_order"))      { *value = label_order(c) ? 1 : 0; return SELHIP_OK; }
+    if (!std::strcmp(name, "join_tile_rows"))   { *value = join_tile_rows(c); return SELHIP_OK; }
+    if (!std::strcmp(name, "chunks"))           { *value = c->n_chunks_last; return SELHIP_OK; }
     return SELHIP_E_BADARG;
 }
 

@@ -205,6 +205,11 @@ class Selector:
     def set_param(self, name: str, value: int):
         check(self._lib.selhip_ctx_set_param(self._ctx, name.encode(), value), self._ctx)
 
+    def get_param(self, name: str) -> int:
+        v = C.c_int(0)
+        check(self._lib.selhip_ctx_get_param(self._ctx, name.encode(), C.byref(v)), self._ctx)
+        return int(v.value)
+
     def set_stage2_grouping(self, enable: bool):
         check(self._lib.selhip_ctx_set_stage2_grouping(self._ctx, 1 if enable else 0), self._ctx)
 

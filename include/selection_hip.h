@@ -161,6 +161,9 @@ int selhip_ctx_set_candidate_begin(selhip_ctx* ctx, int64_t k_min);
  *   "init_cap"    test hook: initial capacity of the candidate / survivor / result lists (they grow and the pass repeats)
  *   "enum_pairs"  test hook: pairs listed per sub-pass when hll_a / hll_an is the first criterion (default 2^26) */
 int selhip_ctx_set_param(selhip_ctx* ctx, const char* name, int value);
+/* what the context decided (read-only): "hll_khi" (largest p = 14 register value + 1; 0 = no bit planes), "hist_bitplanes",
+ * "label_order", "join_tile_rows", "chunks" (chunk lanes of the last pass) */
+int selhip_ctx_get_param(const selhip_ctx* ctx, const char* name, int* value);
 /* Stage 2 grouping (default on): the pairs that reach the HLL-14 stage are bucketed by query row (counting sort) so
  * that waves running side by side on one XCD share their query row in L2.  0 = off (same kernel, list as produced). */
 int selhip_ctx_set_stage2_grouping(selhip_ctx* ctx, int enable);
@@ -236,8 +239,9 @@ int selhip_ctx_last_attempts(const selhip_ctx* ctx);
  * selhip_ctx_kernel_launches: launches of that kernel per pass. */
 double selhip_ctx_kernel_ms(const selhip_ctx* ctx, const char* name);
 double selhip_ctx_kernel_launches(const selhip_ctx* ctx, const char* name);
-/* enable: 0 = off, 1 = every kernel scope, 2 = only the dominant stage-1 kernel ("join" for the signature algorithms,
- * "stage1" otherwise) -- an event pair costs ~10 us of stream time, so level 2 is what a throughput measurement leaves on.
+/* enable: 0 = off, 1 = every kernel scope, 2 = only ONE kernel: the stage-1 kernel ("join" for the signature algorithms,
+ * "stage1" otherwise) or, after selhip_ctx_set_param(ctx, "timed_kernel", 1), stage 2a ("hist") -- an event pair costs ~10 us of
+ * stream time, so level 2 is what a throughput measurement leaves on, on whichever kernel is the longest of the step.
  * Every call resets the accumulated figures. */
 int    selhip_ctx_timing(selhip_ctx* ctx, int enable);
 

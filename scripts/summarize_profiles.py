@@ -101,6 +101,20 @@ if hk and sk:
     t["source"] = "profiles/*_pmc_summary.json (FETCH_SIZE of the stage-2a histogram kernel, calibrated; bytes per pass)"
     tfile.write_text(json.dumps(t, indent=1))
     summary["stage2"] = {"kernel": short(hk[0]), "beyond_l2_bytes_per_pass": per_pass}
+# instruction counts per STEP (all launches of a pass) of the two long kernels, for bench.py's model_vs_pmc fields
+cfile = out / "pmc_counts.json"
+cj = json.loads(cfile.read_text()) if cfile.exists() else {}
+wk = key.split(":")[0]
+passes = sum(len(sq[0][k]["SQ_INSTS_VALU"]) for k in sq[0] if "sig_build_kernel" in k or "cb_bounds_kernel" in k) or 1
+ent = {}
+for label, pat in (("join", ("sigl_join_kernel", "sig16_join_kernel", "sig_join_kernel")), ("hist", ("hll_union_hist_bs", "hll_union_hist_runs"))):
+    ks = [k for k in sq[0] if any(p in k for p in pat) and "SQ_INSTS_VALU" in sq[0][k]]
+    if ks:
+        ent[label] = {"SQ_INSTS_VALU": sum(sum(sq[0][k]["SQ_INSTS_VALU"]) for k in ks) / passes, "kernel": short(ks[0]), "profile": f"profiles/{tag}_pmc_summary.json"}
+if ent:
+    cj[wk] = ent
+    cj["source"] = "rocprofv3 --pmc SQ_INSTS_VALU, wave-instructions per step (scripts/gpu_profile.sh + scripts/summarize_profiles.py)"
+    cfile.write_text(json.dumps(cj, indent=1))
 (out / f"{tag}_pmc_summary.json").write_text(json.dumps(summary, indent=1))
 print(json.dumps(summary.get("stage1")), summary.get("fetch_calibration"))
 for k, e in summary["kernels"].items():
