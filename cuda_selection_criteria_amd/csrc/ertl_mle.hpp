@@ -51,9 +51,19 @@ SELHIP_HD int frexp_exp(double x) {
     return be - 1022;
 }
 
-// log1p: restatement of the fdlibm algorithm (Sun Microsystems, s_log1p.c) that glibc's generic
-// dbl-64 __log1p follows; only reached in the start-point branch hll.h:659 (gprev > 1.5*a), i.e.
-// for sketches whose registers are all near saturation.
+// log1p: restatement of the fdlibm algorithm (s_log1p.c) that glibc's generic dbl-64 __log1p follows; only reached in the
+// start-point branch hll.h:659 (gprev > 1.5*a), i.e. for sketches whose registers are all near saturation.
+// The algorithm, its constants and the structure of the code below come from fdlibm, whose notice is preserved here as its licence asks:
+//
+//   ====================================================
+//   Copyright (C) 1993 by Sun Microsystems, Inc. All rights reserved.
+//
+//   Developed at SunPro, a Sun Microsystems, Inc. business.
+//   Permission to use, copy, modify, and distribute this
+//   software is freely granted, provided that this notice
+//   is preserved.
+//   ====================================================
+//
 SELHIP_HD double log1p_fdlibm(double x) {
     const double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10,
                  two54 = 1.80143985094819840000e+16,

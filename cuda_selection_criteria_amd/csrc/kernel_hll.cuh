@@ -524,7 +524,8 @@ void enum_pairs_kernel(int n, const int* __restrict__ hi, const PassCounters* __
 //   CRIT 2 (hll_an): J = ((double)(e_i+e_k) - U)/U;  C = min(1, (1+Z*sigma_p)*e_k/U) * (1+gamma) * S;  J + C >= tau
 // zs = (double)(float)(Z*sigma_p) and S (= zs for order_n = 1) are computed on the host in float/double exactly as
 // criteria_sketch.hpp:7-20,25-31,39-40 do.  FMA flavour: g++ fuses (1+gamma)*card_B - t_hat_mas (criteria_sketch.hpp:41).
-// The lane's histogram column packs TWO bins per dword (bin k in half k & 1 of word k >> 1): a count is at most 2^p_aux <= 4096, and
+// The lane's histogram column packs TWO bins per dword (bin k in half k & 1 of word k >> 1): a count is at most 2^p_aux <= 32 768
+// (every entry point refuses p_aux > 15: at 16 a pair of empty sketches would put 65 536 into one 16-bit bin), and
 // the adds of one instruction still go to 64 different dwords (one per lane).  8 KiB per one-wave block instead of 16: twice the
 // resident waves, which is what the kernel is short of -- most of a wave's life is the serial f64 solve, not the binning
 // (cfg3's 5e7 pairs with hll_a as first criterion: 5.4 -> 4.8 ms; the kernel is then held at 4 waves per SIMD by its 114 VGPRs).

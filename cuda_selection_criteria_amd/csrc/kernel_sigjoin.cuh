@@ -421,6 +421,54 @@ __device__ __forceinline__ void joinl_accum15(uint32_t (&acc)[T][4], const uint3
     }
 }
 
+// 16-bit "zero half" form ("join_form" = 1, opt-in): the signatures keep all 16 bits and the loop is three 2-cycle instructions per
+// dword -- t = c ^ q, u = t - 0x00010001, acc = acc | (u & ~t) (one v_bitop3_b32: profiles/r03_bitplane_rate.txt, 2.2 cycles alone).
+// (u & ~t) & 0x80008000 != 0 exactly when a half of t is zero (the classic zero-byte test: a borrow can only raise a false flag ABOVE
+// a half that really is zero, so "some half is zero" is exact), and that mask is applied once per row.  Same candidate set as the
+// packed-minimum form.  MEASURED SLOWER (gpurun_out/r03/d_form*: cfg3 112.0 vs 105.9 us, cfg4 2.12 vs 2.03 ms): 101 instructions per
+// row-wave at 2.64 cycles against 69 at 3.7 -- inside the join's loop, beside the LDS broadcast reads, the three-source v_bitop3_b32
+// does not reach its stand-alone rate.  Not the default.
+template <int ND, int T, int OFF, int CNT>
+__device__ __forceinline__ void joinl_accum_z(uint32_t (&acc)[T][4], const uint32_t (&c)[T][ND], const uint32_t (&q)[CNT], uint32_t k1) {
+#pragma unroll
+    for (int d = 0; d < CNT; d += 4) {
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+            uint32_t x[4], u[4];
+#pragma unroll
+            for (int a = 0; a < 4; ++a) asm("v_xor_b32 %0, %1, %2" : "=v"(x[a]) : "v"(c[t][OFF + d + a]), "v"(q[d + a]));
+#pragma unroll
+            for (int a = 0; a < 4; ++a) asm("v_sub_u32 %0, %1, %2" : "=v"(u[a]) : "v"(x[a]), "v"(k1));
+#pragma unroll
+            for (int a = 0; a < 4; ++a) acc[t][a] = __builtin_amdgcn_bitop3_b32(acc[t][a], u[a], x[a], 0xF4);     // a | (b & ~c)
+        }
+    }
+}
+
+template <int T>
+__device__ __forceinline__ void joinl_reset_z(uint32_t (&acc)[T][4]) {
+#pragma unroll
+    for (int t = 0; t < T; ++t)
+#pragma unroll
+        for (int a = 0; a < 4; ++a) acc[t][a] = 0u;
+}
+
+template <int T>
+__device__ __forceinline__ void joinl_test_z(const uint32_t (&acc)[T][4], int i, int k0, int lane, int z0, int n,
+                                             const int* hi_rows, int r, WaveAppender& app) {
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+        const uint32_t f = ((acc[t][0] | acc[t][1]) | (acc[t][2] | acc[t][3])) & 0x80008000u;
+        const u64 mm = __ballot(f != 0u);
+        if (mm) {
+            const int lo = max(i + 1, z0);
+            const int hk = min(hi_rows[r], n - 1);
+            const int k = k0 + t * kWave;
+            app.push(((mm >> lane) & 1ull) && k >= lo && k <= hk, i, k, lane);
+        }
+    }
+}
+
 template <int T>
 __device__ __forceinline__ void joinl_reset15(uint32_t (&acc)[T][4]) {
 #pragma unroll
@@ -491,12 +539,39 @@ __device__ unsigned long long g_join_trace[1 << 17][4];
 #endif
 constexpr int kJoinTilePadRows = 2;        // look-ahead reads past the last staged row stay inside the allocation
 
-template <int ND, int T, int WPB, bool SIG15>
+// Which (tile of query rows, block of 256 candidates) unit a block of the LDS-tile join takes.  The plain grid is the rectangle
+// tiles x candidate blocks, and on the triangle i < k the blocks under the diagonal leave at once -- but they are dispatched first
+// (candidate blocks ascending: block column g has only ~g * 256 / qt tiles above the diagonal), 37 700 dead waves of 50 080 at cfg3,
+// and the waves that do work start late: the timeline (profiles/r02_join_timeline.txt) shows the last of them starting 55 us into a
+// 104 us kernel.  For contiguous rows (one part, first row a multiple of the tile height, tile height dividing 256) column g holds
+//     count(g) = min(n_tiles, c0 + a g),   a = 256 / qt,   c0 = a (g_lo + 1) - row_begin / qt
+// units, so the grid is launched with exactly the sum of those and a block finds its unit from the closed form of the partial sums
+// (a square root and a fix-up).  a == 0: the rectangle (interleaved row blocks of the multi-GPU partition, odd tile heights).
+// MEASURED (gpurun_out/r03/d_tri*): cfg3 join 107.0 vs 106.6 us, cfg4 2.009 vs 2.013 ms -- nothing.  The late
+// starts of the timeline are not dispatch time lost on dead blocks: 12 400 working wave-units meet 8 192 wave slots, so a third of
+// them can only start when a first-round wave ends (~45-55 us in).  Kept behind "join_tri" = 1 (tested), not the default.
+struct JoinTriangle {
+    int a, c0, K, SK;          // K columns grow by `a` units each (SK units together), the rest hold n_tiles
+    __device__ __forceinline__ long long upto(int k) const { return (long long)k * c0 + (long long)a * k * (k - 1) / 2; }
+    __device__ __forceinline__ void unit(int b, int n_tiles, int* tile, int* col) const {
+        if (a == 0) { *tile = b % n_tiles; *col = b / n_tiles; return; }
+        if (b >= SK) { *tile = (b - SK) % n_tiles; *col = K + (b - SK) / n_tiles; return; }
+        const double h = (double)c0 - 0.5 * (double)a;
+        int k = (int)((sqrt(h * h + 2.0 * (double)a * (double)b) - h) / (double)a);
+        k = max(0, min(k, K - 1));
+        while (k + 1 < K && upto(k + 1) <= b) ++k;
+        while (k > 0 && upto(k) > b) --k;
+        *tile = b - (int)upto(k); *col = k;
+    }
+};
+
+// FORM: 0 = packed minimum (v_xor_b32 + v_pk_min_u16), 1 = 15-bit signatures with flag arithmetic, 2 = 16-bit zero-half test
+template <int ND, int T, int WPB, int FORM>
 __global__ __launch_bounds__(WPB * kWave)
 void sigl_join_kernel(const uint32_t* __restrict__ sigP, const uint32_t* __restrict__ sigG, int n, int n_pad,
                       const int* __restrict__ hi, const PassCounters* __restrict__ pc_in,
                       RowMap rm, int n_tiles, int group_base, int qt,
-                      selhip_int2_t* __restrict__ pre, u64 pre_cap, u64* __restrict__ seg_cnt, int cb_pruned) {
+                      selhip_int2_t* __restrict__ pre, u64 pre_cap, u64* __restrict__ seg_cnt, int cb_pruned, JoinTriangle tri) {
     extern __shared__ __attribute__((aligned(16))) uint32_t joinl_smem[];
     selhip_int2_t* const app_lds = reinterpret_cast<selhip_int2_t*>(joinl_smem);                  // WPB * kAppendCap records
     int* const hi_lds = reinterpret_cast<int*>(joinl_smem + WPB * kAppendCap * 2);                // hi[] of the tile's rows
@@ -506,8 +581,9 @@ void sigl_join_kernel(const uint32_t* __restrict__ sigP, const uint32_t* __restr
 #ifdef SELHIP_JOIN_TRACE
     const unsigned long long trace_t0 = wall_clock64();
 #endif
-    const int tile = blockIdx.x % n_tiles;
-    const int grp_b = group_base + (blockIdx.x / n_tiles) * (WPB * T);                            // the block's first candidate group
+    int tile, col;
+    tri.unit((int)blockIdx.x, n_tiles, &tile, &col);
+    const int grp_b = group_base + col * (WPB * T);                                               // the block's first candidate group
     // (walking the candidate blocks from the highest ranks down, so that the grid tapers off on the short columns, was measured:
     //  cfg3 119 vs 109 us -- kept in ascending order.  So was a grid resident all at once with the valid (tile, candidate block)
     //  units dealt out in equal contiguous shares -- tiles of 16 / 32 / 64 rows double-buffered in LDS, candidates reloaded only when
@@ -570,13 +646,13 @@ void sigl_join_kernel(const uint32_t* __restrict__ sigP, const uint32_t* __restr
     constexpr int CH = ND < 16 ? ND : 16;                                      // dwords per chunk (one register set)
     constexpr int NCH = ND / CH;                                               // chunks per row: 1 (<= 32 bands), 2 (64), 4 (128)
     const int rows = i_hi - i_lo;
-    using acc_t = typename std::conditional<SIG15, uint32_t, us2_t>::type;
+    using acc_t = typename std::conditional<FORM != 0, uint32_t, us2_t>::type;
     acc_t acc[T][4];
-    uint32_t k7 = 0x7FFF7FFFu;
+    uint32_t k7 = FORM == 2 ? 0x00010001u : 0x7FFF7FFFu;
     asm volatile("" : "+v"(k7));                                               // keep the constant in a VGPR (a literal operand is not a plain VOP2)
-#define SELHIP_JL_RESET()            do { if constexpr (SIG15) joinl_reset15<T>(acc); else joinl_reset<T>(acc); } while (0)
-#define SELHIP_JL_ACCUM(OFF, Q)      do { if constexpr (SIG15) joinl_accum15<ND, T, OFF, CH>(acc, c, Q, k7); else joinl_accum<ND, T, OFF, CH>(acc, c, Q); } while (0)
-#define SELHIP_JL_TEST(R)            do { if constexpr (SIG15) joinl_test15<T>(acc, i_lo + (R), k0, lane, z0, n, hi_lds, R, app); else joinl_test<T>(acc, i_lo + (R), k0, lane, z0, n, hi_lds, R, app); } while (0)
+#define SELHIP_JL_RESET()            do { if constexpr (FORM == 2) joinl_reset_z<T>(acc); else if constexpr (FORM == 1) joinl_reset15<T>(acc); else joinl_reset<T>(acc); } while (0)
+#define SELHIP_JL_ACCUM(OFF, Q)      do { if constexpr (FORM == 2) joinl_accum_z<ND, T, OFF, CH>(acc, c, Q, k7); else if constexpr (FORM == 1) joinl_accum15<ND, T, OFF, CH>(acc, c, Q, k7); else joinl_accum<ND, T, OFF, CH>(acc, c, Q); } while (0)
+#define SELHIP_JL_TEST(R)            do { if constexpr (FORM == 2) joinl_test_z<T>(acc, i_lo + (R), k0, lane, z0, n, hi_lds, R, app); else if constexpr (FORM == 1) joinl_test15<T>(acc, i_lo + (R), k0, lane, z0, n, hi_lds, R, app); else joinl_test<T>(acc, i_lo + (R), k0, lane, z0, n, hi_lds, R, app); } while (0)
     uint32_t qa[CH], qb[CH];
     joinl_load<CH>(qa, tile_lds);
     if constexpr (NCH == 1) {

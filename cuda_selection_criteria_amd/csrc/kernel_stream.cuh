@@ -75,8 +75,8 @@ __device__ __forceinline__ bool stream_band_pass(const u64x2 (&cand)[NCH], const
 
 // ---------------------------------------------------------------------------------------------
 // smh_stream_kernel<NCH, LOG2R>: m = 128*NCH buckets, bands of 2^LOG2R rows.
-//   block  = 4 waves; one block = (query tile of Q = 28/NCH rows) x (chunk of kChunk candidates)
-//   LDS    = the Q query sketches (28 KiB), staged once per block with coalesced 16-B loads, then copied to VGPRs by each wave
+//   block  = 4 waves; one block = (query tile of Q = 24/NCH rows, kQueryVgprBudget) x (chunk of kChunk candidates)
+//   LDS    = the Q query sketches (24 KiB), staged once per block with coalesced 16-B loads, then copied to VGPRs by each wave
 //   stream = each wave walks its candidates (stride 4), NCH x global_load_dwordx4 (1 KiB each) per candidate, kStreamAhead candidates ahead
 // blockIdx.x -> (tile = b % n_tiles, chunk = b / n_tiles): blocks b and b+8 (same XCD under round-robin
 // dispatch) work on the same candidate chunk, so the chunk is served by that XCD's L2.

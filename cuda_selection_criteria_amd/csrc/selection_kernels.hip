@@ -36,6 +36,7 @@
 #include <vector>
 
 #include "../../include/selection_hip.h"
+#include "selhip_internal.h"
 #include "ertl_mle.hpp"
 #include "synth.hpp"
 
@@ -100,6 +101,7 @@ constexpr int kMaxChunks = 8;
 constexpr size_t kSegCounterSlots = (size_t)(kMaxChunks + 1) * kAppendSegs * kSegStride;    // the join's append-segment counters (u64 slots)
 constexpr double kAutoChunkPairs = 1e9;  // pairs per pass from which the automatic setting splits a pass into two chunk lanes
 static_assert(kCounterBlocks == kMaxChunks + 1, "common.cuh: counter blocks per pass");
+constexpr int kMaxAuxP = SELHIP_MAX_AUX_P;   // auxiliary HLL precision accepted by every entry point: aux_fused_kernel counts in 16-bit bins (a bin holds up to 2^p_aux)
 constexpr long long kEnumPairs = 1ll << 26;    // hll_a / hll_an as first criterion: pairs listed per sub-pass (512 MiB of int2)
 
 enum { T_PREP = 0, T_STAGE1, T_HIST, T_SELECT, T_TOTAL, T_SIGBUILD, T_JOIN, T_VERIFY, T_AUX, T_GROUP, T_COUNT };
@@ -130,6 +132,8 @@ struct selhip_ctx {
     DevBuf<PassCounters> pc;            // TWO sets of kMaxChunks + 1 counter blocks: pass k uses set k & 1 and its first kernel clears the other
     PassCounters* pcb = nullptr;        // the set of the pass enqueued last
     int pc_flip = 0;
+    bool pc_dirty = false;              // a pass claimed a counter set and did not get to the end of its enqueue (or the stream changed): clear both sets first
+    int fail_after_flip = 0;            // test hook ("fail_after_flip"): the next enqueue returns an error right after claiming its counter set
     DevBuf<u64> seg_cnt;                // the join's append-segment counters: (kMaxChunks + 1) x kAppendSegs x kSegStride
     DevBuf<selhip_int2_t> surv;
     DevBuf<uint32_t> counts;
@@ -172,9 +176,13 @@ struct selhip_ctx {
     int verify_fb = 0;                  // test hook: force the collision fallback of verify16_kernel
     int join_wpb = 4;                   // 16-bit join: waves per block (DPP form: 1 or 4; LDS form: 4 or 8 -- the waves of a block share the staged query tile)
     int join_db = 1;                    // 16-bit join: double-buffered query batches
+    int join_tri = 0;                   // LDS-tile join: 1 = launch only the (tile, candidate block) units above the diagonal (measured: no gain, see JoinTriangle); 0 = the rectangle
+    int join_form = 0;                  // 16-bit LDS-tile join, inner loop: 0 = xor + v_pk_min_u16, 1 = zero-half test (xor, sub, v_bitop3_b32; measured slower, see kernel_sigjoin.cuh)
     int join_bits = 16;                 // signature width of the all-pairs join: 16 (packed min), 15 (LDS form only: flag arithmetic, all plain VOP2) or 32
     int join_q = 1;                     // 16-bit join, query side: 1 = tile staged in LDS, broadcast reads (sigl_join_kernel), 0 = DPP row broadcast (sig16_join_kernel)
     long long enum_pairs = kEnumPairs;  // hll_a / hll_an as first criterion: pairs listed per sub-pass (test hook "enum_pairs")
+    int sig_cache = 0;                  // keep the band signatures across passes ("sig_cache"); sig_key = what the arrays hold (0 = nothing)
+    long long sig_key = 0;
     int sig_tile = 1;                   // signature build: tiled form (0 = one thread per bucket, the round-1 kernel)
     int init_cap = 0;                   // test hook: initial capacity of the survivor / candidate lists (0 = sized from the workload)
     int join_qt = 0;                    // query rows per signature-join block (multiple of 16); 0 = automatic: 32 rows below 1e8 pairs per pass, 64 up to 4.5e8
@@ -411,18 +419,33 @@ hipError_t launch_joinl_w(selhip_ctx* c, const StageIO& io, int n_pad, const Row
     const int n_groups = (n + kWave - 1) / kWave - group_base;
     const int n_gblocks = (n_groups + GPB - 1) / GPB;
     if (n_tiles <= 0 || n_gblocks <= 0) return hipSuccess;
-    const long long blocks = (long long)n_tiles * n_gblocks;
+    long long blocks = (long long)n_tiles * n_gblocks;
+    // only the units above the diagonal (JoinTriangle, kernel_sigjoin.cuh) when the rows are contiguous and the tiles line up with the
+    // 256-candidate blocks; otherwise the rectangle, whose blocks under the diagonal leave at once
+    JoinTriangle tri{0, 0, 0, 0};
+    constexpr int kCand = GPB * kWave;
+    if (c->join_tri && rm.n_parts == 1 && kCand % qt == 0 && rm.row_begin % qt == 0 && blocks < 0x7FFFFFFFll) {
+        const int a = kCand / qt, g_lo = group_base / GPB, rbq = rm.row_begin / qt;
+        const long long c0 = (long long)a * (g_lo + 1) - rbq;
+        if (c0 >= 1) {
+            // columns k = 0 .. K-1 hold c0 + a k < n_tiles units
+            long long K = c0 >= n_tiles ? 0 : ((long long)n_tiles - c0 + a - 1) / a;
+            K = std::min<long long>(K, n_gblocks);
+            const long long SK = K * c0 + (long long)a * K * (K - 1) / 2;
+            const long long total = SK + (long long)(n_gblocks - K) * n_tiles;
+            if (total > 0 && total < 0x7FFFFFFFll) { tri = JoinTriangle{a, (int)c0, (int)K, (int)SK}; blocks = total; }
+        }
+    }
     if (blocks > 0x7FFFFFFFll) return hipErrorInvalidValue;
     const size_t smem = (size_t)WPB * kAppendCap * sizeof(selhip_int2_t) + (size_t)((qt + 3) & ~3) * 4 + (size_t)(qt + kJoinTilePadRows) * ND * 4;
     if (smem > 64 * 1024) return hipErrorInvalidValue;                                   // join_qt is capped so that this cannot happen
-    if (c->join_bits == 15)
-        hipLaunchKernelGGL((sigl_join_kernel<ND, T, WPB, true>), dim3((unsigned)blocks), dim3(WPB * kWave), smem, io.st,
-                           c->sigP.p, c->sigG.p, n, n_pad, c->hi.p, c->pcb, rm, n_tiles, group_base, qt,
-                           io.cand, io.cap, io.seg_cnt, c->mode == SELHIP_MODE_CB_SMH ? 1 : 0);
-    else
-        hipLaunchKernelGGL((sigl_join_kernel<ND, T, WPB, false>), dim3((unsigned)blocks), dim3(WPB * kWave), smem, io.st,
-                           c->sigP.p, c->sigG.p, n, n_pad, c->hi.p, c->pcb, rm, n_tiles, group_base, qt,
-                           io.cand, io.cap, io.seg_cnt, c->mode == SELHIP_MODE_CB_SMH ? 1 : 0);
+#define SELHIP_JOINL_LAUNCH(FORM) hipLaunchKernelGGL((sigl_join_kernel<ND, T, WPB, FORM>), dim3((unsigned)blocks), dim3(WPB * kWave), smem, io.st, \
+                           c->sigP.p, c->sigG.p, n, n_pad, c->hi.p, c->pcb, rm, n_tiles, group_base, qt, \
+                           io.cand, io.cap, io.seg_cnt, c->mode == SELHIP_MODE_CB_SMH ? 1 : 0, tri)
+    if (c->join_bits == 15)    SELHIP_JOINL_LAUNCH(1);
+    else if (c->join_form == 0) SELHIP_JOINL_LAUNCH(0);
+    else                        SELHIP_JOINL_LAUNCH(2);
+#undef SELHIP_JOINL_LAUNCH
     return hipGetLastError();
 }
 
@@ -449,7 +472,14 @@ hipError_t launch_sig_build(selhip_ctx* c, int n_rows, int n_bands, bool with_bo
     // tiled build (kSigTileG genomes per block, LDS transpose) for the shapes of the all-pairs joins; the per-bucket form otherwise
     const bool tile_mode = is_pow2(c->m) && is_pow2(n_bands) && n_bands <= 128 && n_rows >= 2 && n_rows <= 32 && c->m >= 4 && c->sig_tile;
     const long long threads = n_rows <= kWave ? (long long)n * c->m : (long long)n * n_bands;
-    const unsigned work_blocks = tile_mode ? (unsigned)((n + kSigTileG - 1) / kSigTileG) : (unsigned)((threads + kBlock - 1) / kBlock);
+    // "sig_cache": the signatures depend on the sketches and the band shape only, so a context that runs many passes over the same
+    // sketches (the ranks of a strong-scaled job, a threshold sweep) builds them once; upload / attach and any reallocation of the
+    // signature arrays invalidate them.  The bounds blocks still run every pass (they depend on tau, the mode and the rows).
+    const long long sig_key = ((long long)n_rows << 40) | ((long long)n_bands << 20) | ((long long)(c->join_bits == 15) << 2) | (tile_mode ? 2 : 0) | 1;
+    const bool cached = c->sig_cache && c->sig_key == sig_key && with_bounds;
+    const unsigned work_blocks = cached ? 0u : tile_mode ? (unsigned)((n + kSigTileG - 1) / kSigTileG) : (unsigned)((threads + kBlock - 1) / kBlock);
+    c->sig_key = c->sig_cache ? sig_key : 0;
+    if (work_blocks + (unsigned)bounds_blocks == 0) return hipSuccess;
     hipLaunchKernelGGL(sig_build_kernel, dim3(work_blocks + (unsigned)bounds_blocks), dim3(kBlock), 0, c->stream,
                        c->d_aux, n, c->m, n_rows, n_bands, n_pad, c->sigQ.p, c->sigT.p, c->sigP.p, c->sigG.p,
                        bounds_blocks, c->d_cards, tau, c->mode == SELHIP_MODE_CB_SMH ? 1 : 0, row_map(c, rb, re), c->ecard.p, c->hi.p, c->pcb,
@@ -823,10 +853,17 @@ int enqueue_pass(selhip_ctx* c) {
     // counter set of this pass (block 0: z0, evaluated, results; blocks 1.. : one per row chunk); the other set is cleared by
     // this pass's first kernel for the next pass -- no memset dispatch on the stream.  (Chosen only now: nothing above launches, and
     // an argument error must not consume a set that no kernel has cleared.)
+    if (c->pc_dirty) {
+        // the previous enqueue failed after it had claimed its counter set (its first kernel, which clears the other set for this pass,
+        // may never have run), or the stream changed behind the initial memset: clear both sets here, once
+        HIPCHK(&c->err, hipMemsetAsync(c->pc.p, 0, sizeof(PassCounters) * 2 * (kMaxChunks + 1), c->stream));
+    }
     c->pcb = c->pc.p + (size_t)c->pc_flip * (kMaxChunks + 1);
     PassCounters* const pc_next = c->pc.p + (size_t)(c->pc_flip ^ 1) * (kMaxChunks + 1);
     c->pc_flip ^= 1;
+    c->pc_dirty = true;                                  // until this function returns SELHIP_OK
     PassCounters* pc0 = c->pcb;
+    if (c->fail_after_flip) { c->fail_after_flip = 0; set_err(&c->err, "test hook: enqueue failed after the counter flip"); return SELHIP_E_HIP; }
     if (use_sig) {
         // bounds (truncated cards, CB cut-offs, z0, evaluated count) ride in the first blocks of the signature build
         HIPCHK(&c->err, launch_sig_build(c, c->n_rows, c->n_bands, true, tau, rb, re, pc_next));
@@ -892,6 +929,7 @@ int enqueue_pass(selhip_ctx* c) {
         HIPCHK(&c->err, hipEventRecord(c->ev_end, lane[1]));
         HIPCHK(&c->err, hipStreamWaitEvent(c->stream, c->ev_end, 0));
         HIPCHK(&c->err, hipMemcpyAsync(c->h_pc, c->pcb, sizeof(PassCounters) * (kMaxChunks + 1), hipMemcpyDeviceToHost, c->stream));
+        c->pc_dirty = false;
         return SELHIP_OK;
     }
 
@@ -946,6 +984,7 @@ int enqueue_pass(selhip_ctx* c) {
     // (handing the counters to the host from the last block of the final kernel instead of this copy was tried: the 1 024
     // "block done" atomics on one address cost 16 us, the copy dispatch 4)
     HIPCHK(&c->err, hipMemcpyAsync(c->h_pc, c->pcb, sizeof(PassCounters) * (kMaxChunks + 1), hipMemcpyDeviceToHost, c->stream));
+    c->pc_dirty = false;
     return SELHIP_OK;
 }
 
@@ -983,6 +1022,8 @@ int ensure_scratch(selhip_ctx* c, size_t surv_cap, size_t res_cap) {
         const bool sig_path = hash || ((c->algo == SELHIP_ALGO_SIG || c->algo == SELHIP_ALGO_AUTO) && sig_supported(c->m, c->n_rows, c->n_bands));
         if (smh && !sig_path && stream_supported(c->m, c->n_rows)) HIPCHK(&c->err, c->aux_il.ensure((size_t)c->n * c->m));
         if (nb <= 128 || hash) {
+            const uint32_t* const old_sig[4] = {c->sigQ.p, c->sigT.p, c->sigP.p, c->sigG.p};
+            struct SigGuard { selhip_ctx* c; const uint32_t* const* o; ~SigGuard() { if (c->sigQ.p != o[0] || c->sigT.p != o[1] || c->sigP.p != o[2] || c->sigG.p != o[3]) c->sig_key = 0; } } guard{c, old_sig};
             HIPCHK(&c->err, c->sigQ.ensure((size_t)c->n * nb));
             HIPCHK(&c->err, c->sigT.ensure(n_pad * nb));
             HIPCHK(&c->err, c->sigP.ensure(n_pad * (size_t)((nb + 1) / 2)));
@@ -1079,6 +1120,11 @@ void selhip_ctx_destroy(selhip_ctx* c) {
 
 int selhip_ctx_set_stream(selhip_ctx* c, void* hip_stream) {
     if (!c) return SELHIP_E_BADARG;
+    if (c->stream != (hipStream_t)hip_stream && c->pc.p) {
+        // the counter sets were cleared by work on the old stream, which the new one is not ordered behind
+        (void)hipStreamSynchronize(c->stream);
+        c->pc_dirty = true;
+    }
     c->stream = (hipStream_t)hip_stream;
     return SELHIP_OK;
 }
@@ -1100,6 +1146,12 @@ int selhip_ctx_set_row_interleave(selhip_ctx* c, int block_rows, int n_parts, in
     return SELHIP_OK;
 }
 
+// Names beyond the documented ones (include/selection_hip.h) -- hooks of the test-suite and measurement knobs, not interface:
+//   "verify_fb"        1 sends every candidate through the hash-collision fallback of the verification
+//   "init_cap"         initial capacity of the candidate / survivor / result lists (they grow and the pass repeats)
+//   "enum_pairs"       pairs listed per sub-pass when hll_a / hll_an is the first criterion (default 2^26)
+//   "fail_after_flip"  the next enqueue fails right after claiming its counter set (recovery of the double-buffered counters)
+//   "hist_pad"         extra LDS bytes per block of the byte-row stage-2a kernel (lowers the resident waves per CU)
 int selhip_ctx_set_param(selhip_ctx* c, const char* name, int value) {
     if (!c || !name) return SELHIP_E_BADARG;
     if (!std::strcmp(name, "join_qt")) {
@@ -1108,14 +1160,18 @@ int selhip_ctx_set_param(selhip_ctx* c, const char* name, int value) {
         return SELHIP_OK;
     }
     if (!std::strcmp(name, "verify_fb")) { c->verify_fb = value != 0; return SELHIP_OK; }
+    if (!std::strcmp(name, "fail_after_flip")) { c->fail_after_flip = value != 0; return SELHIP_OK; }
     if (!std::strcmp(name, "join_wpb")) {
         if (value != 1 && value != 4 && value != 8) { set_err(&c->err, "join_wpb must be 1, 4 or 8"); return SELHIP_E_BADARG; }
         c->join_wpb = value;
         return SELHIP_OK;
     }
+    if (!std::strcmp(name, "join_form")) { c->join_form = value != 0; return SELHIP_OK; }
+    if (!std::strcmp(name, "join_tri")) { c->join_tri = value != 0; return SELHIP_OK; }
     if (!std::strcmp(name, "join_db")) { c->join_db = value != 0; return SELHIP_OK; }
     if (!std::strcmp(name, "join_q")) { c->join_q = value != 0; return SELHIP_OK; }
-    if (!std::strcmp(name, "sig_tile")) { c->sig_tile = value != 0; return SELHIP_OK; }
+    if (!std::strcmp(name, "sig_tile")) { c->sig_tile = value != 0; c->sig_key = 0; return SELHIP_OK; }
+    if (!std::strcmp(name, "sig_cache")) { c->sig_cache = value != 0; c->sig_key = 0; return SELHIP_OK; }
     if (!std::strcmp(name, "enum_pairs")) {
         if (value < 1) { set_err(&c->err, "enum_pairs must be >= 1"); return SELHIP_E_BADARG; }
         c->enum_pairs = value;
@@ -1208,7 +1264,7 @@ int selhip_ctx_set_criterion(selhip_ctx* c, int criterion) {
 }
 
 int selhip_ctx_upload_aux_hll(selhip_ctx* c, const uint8_t* h_aux_hll, int p_aux) {
-    if (!c || !h_aux_hll || p_aux < 4 || p_aux > 16) return SELHIP_E_BADARG;
+    if (!c || !h_aux_hll || p_aux < 4 || p_aux > kMaxAuxP) return SELHIP_E_BADARG;     // (aux_fused_kernel's bins are 16 bits wide)
     if (!c->d_hll && c->n) { set_err(&c->err, "upload the primary sketches first"); return SELHIP_E_STATE; }
     HIPCHK(&c->err, hipSetDevice(c->device));
     const size_t bytes = (size_t)c->n << p_aux;
@@ -1220,7 +1276,7 @@ int selhip_ctx_upload_aux_hll(selhip_ctx* c, const uint8_t* h_aux_hll, int p_aux
 }
 
 int selhip_ctx_attach_aux_hll(selhip_ctx* c, const uint8_t* d_aux_hll, int p_aux) {
-    if (!c || !d_aux_hll || p_aux < 4 || p_aux > 16) return SELHIP_E_BADARG;
+    if (!c || !d_aux_hll || p_aux < 4 || p_aux > kMaxAuxP) return SELHIP_E_BADARG;
     c->d_aux_hll = d_aux_hll; c->p_aux = p_aux;
     return SELHIP_OK;
 }
@@ -1272,7 +1328,7 @@ int selhip_ctx_upload(selhip_ctx* c, const uint8_t* h_hll, const uint64_t* h_aux
     int rc = validate_shape(c, n, m, p_hll);
     if (rc) return rc;
     if (n > 0 && (!h_hll || !h_aux)) { set_err(&c->err, "null sketch pointer"); return SELHIP_E_BADARG; }
-    c->n = n; c->m = m; c->p = p_hll; c->have_run = false; c->pending = false; c->cand_begin = 0;
+    c->n = n; c->m = m; c->p = p_hll; c->have_run = false; c->pending = false; c->cand_begin = 0; c->sig_key = 0;
     const size_t hb = (size_t)1 << p_hll;
     if (n > 0) {
         HIPCHK(&c->err, c->own_hll.ensure((size_t)n * hb));
@@ -1293,7 +1349,7 @@ int selhip_ctx_attach(selhip_ctx* c, const uint8_t* d_hll, const uint64_t* d_aux
     if (rc) return rc;
     if (n > 0 && (!d_hll || !d_aux)) { set_err(&c->err, "null sketch pointer"); return SELHIP_E_BADARG; }
     if (((uintptr_t)d_hll & 15) || ((uintptr_t)d_aux & 15)) { set_err(&c->err, "sketch pointers must be 16-byte aligned"); return SELHIP_E_BADARG; }
-    c->n = n; c->m = m; c->p = p_hll; c->have_run = false; c->pending = false; c->cand_begin = 0;
+    c->n = n; c->m = m; c->p = p_hll; c->have_run = false; c->pending = false; c->cand_begin = 0; c->sig_key = 0;
     c->d_hll = d_hll; c->d_aux = (const u64*)d_aux; c->owns_sketches = false;
     c->d_aux_hll = nullptr; c->p_aux = 0;
     return after_sketches(c, d_cards, false);
@@ -1376,7 +1432,9 @@ int selhip_ctx_finish(selhip_ctx* c) {
             // the 16-bit join's list is kAppendSegs equal slices: it overflows when its fullest slice does
             const u64 worst = std::max(std::max(std::max(q.n_survivors, q.n_candidates), q.n_pre_segmax * (u64)kAppendSegs), c->criterion != SELHIP_CRIT_SMH_A ? q.n_final : 0);
             if (worst > slice) { surv_cap = std::max(surv_cap, (size_t)((worst + worst / 8 + 1024) * (u64)chunks)); grow = true; }
-            if (q.n_aux_in > c->cand.cap) { c->pending = false; set_err(&c->err, "internal: enumerated pair list overflow"); return SELHIP_E_OVERFLOW; }
+            // (n_aux_in is zeroed before every enumeration sub-pass, so what arrives here is the LAST sub-pass's count only: it proves
+            //  nothing about the others.  The guarantee is the host-side bound in enqueue_pass -- every sub-pass lists at most
+            //  cand.cap - 1024 pairs by construction -- and enum_pairs_kernel never writes past out_cap.)
         }
         if (pc.n_results > c->results.cap) { res_cap = (size_t)(pc.n_results + pc.n_results / 8 + 1024); grow = true; }
         if (!grow) {
@@ -1736,274 +1794,35 @@ int launch_kernel_CBsmh64(const uint8_t* main_sketches, const uint64_t* aux_sket
                                              reinterpret_cast<unsigned long long*>(out_count));
 }
 
-// ---------------------------------------------------------------------------------------------------
-// Multi-GPU entry taking a device list (one host thread per device inside ONE process): the pair space is sharded by
-// query rows (equal pair counts), every device holds a full replica of the sketches, and the only exchange step is
-// the gather of the selected-pair records -- RCCL all_gather over xGMI (counts first, then max-count-sized framed
-// buffers), librccl loaded with dlopen so that single-GPU users never pay for it.  (bench.py uses the equivalent
-// process-per-GPU layout through torch.distributed.)
-// ---------------------------------------------------------------------------------------------------
-}  // extern "C"
+// (selhip_multi_select lives in selhip_multi.hip, selhip_ooc_select in selhip_ooc.hip: host-only translation units of this library
+// built on the context API above; what they need beyond it is declared in selhip_internal.h and defined here)
+void selhip_internal_set_error(const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+}
 
-#include <dlfcn.h>
-#include <thread>
-
-namespace {
-
-struct Rccl {
-    void* lib = nullptr;
-    int (*CommInitAll)(void**, int, const int*) = nullptr;
-    int (*CommDestroy)(void*) = nullptr;
-    int (*AllGather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
-    const char* (*GetErrorString)(int) = nullptr;
-    bool load() {
-        if (lib) return true;
-        for (const char* name : {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"}) {
-            lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
-            if (lib) break;
-        }
-        if (!lib) return false;
-        CommInitAll = (int (*)(void**, int, const int*))dlsym(lib, "ncclCommInitAll");
-        CommDestroy = (int (*)(void*))dlsym(lib, "ncclCommDestroy");
-        AllGather = (int (*)(const void*, void*, size_t, int, void*, hipStream_t))dlsym(lib, "ncclAllGather");
-        GetErrorString = (const char* (*)(int))dlsym(lib, "ncclGetErrorString");
-        return CommInitAll && CommDestroy && AllGather && GetErrorString;
+int selhip_internal_reserve_replica(selhip_ctx* c, int64_t rows_padded, int m, int p_hll, int p_aux,
+                                    uint8_t** d_hll, uint64_t** d_aux, double** d_cards, uint8_t** d_aux_hll) {
+    if (!c || rows_padded < 0 || m <= 0 || p_hll < 4 || p_hll > 20 || !d_hll || !d_aux || !d_cards) return SELHIP_E_BADARG;
+    HIPCHK(&c->err, hipSetDevice(c->device));
+    const size_t rows = (size_t)std::max<int64_t>(rows_padded, 1);
+    HIPCHK(&c->err, c->own_hll.ensure(rows << p_hll));
+    HIPCHK(&c->err, c->own_aux.ensure(rows * (size_t)m));
+    HIPCHK(&c->err, c->own_cards.ensure(rows));
+    *d_hll = c->own_hll.p; *d_aux = (uint64_t*)c->own_aux.p; *d_cards = c->own_cards.p;
+    if (p_aux > 0) {
+        if (!d_aux_hll || p_aux > kMaxAuxP) return SELHIP_E_BADARG;
+        HIPCHK(&c->err, c->own_aux_hll.ensure(rows << p_aux));
+        *d_aux_hll = c->own_aux_hll.p;
     }
-};
-Rccl g_rccl;
-constexpr int kNcclChar = 0;     // ncclDataType_t ncclChar (rccl.h)
-
-}  // namespace
-
-extern "C" {
-
-// ---- out-of-core driver ------------------------------------------------------------
-namespace {
-struct OocWorker {
-    selhip_ctx* ctx = nullptr;
-    uint8_t* d_hll = nullptr; u64* d_aux = nullptr; double* d_cards = nullptr; uint8_t* d_aux_hll = nullptr;
-    int64_t resident_i = -1;                     // block whose rows sit at the front of the buffers
-    std::vector<selhip_pair_t> out;
-    int64_t stats[4] = {0, 0, 0, 0};
-    int rc = 0;
-    std::string err;
-};
-}  // namespace
-
-int selhip_ooc_select(int device, const uint8_t* h_hll, const uint64_t* h_aux, const double* h_cards,
-                      const uint8_t* h_aux_hll, int p_aux, int criterion,
-                      int64_t n, int m, int p_hll, int mode, int algo, int fp_mode, float tau_f, int n_rows, int n_bands,
-                      int64_t block_genomes, int n_streams,
-                      selhip_pair_t* h_out, int64_t cap, int64_t* count_out, int64_t stats_out[4]) {
-    if (!count_out || cap < 0 || (cap && !h_out) || n < 0 || block_genomes < 1 || n_streams < 1 || n_streams > 4) { set_err(nullptr, "bad argument"); return SELHIP_E_BADARG; }
-    if (n > 0 && (!h_hll || !h_aux || !h_cards)) { set_err(nullptr, "the out-of-core driver needs host sketches and their cardinalities"); return SELHIP_E_BADARG; }
-    const bool need_aux_hll = criterion != SELHIP_CRIT_SMH_A;
-    if (need_aux_hll && (!h_aux_hll || p_aux < 4 || p_aux > 12)) { set_err(nullptr, "criterion %d needs auxiliary HLL sketches", criterion); return SELHIP_E_BADARG; }
-    if (block_genomes * 2 > 0x7FFFFFF0ll) { set_err(nullptr, "block too large"); return SELHIP_E_BADARG; }
-    *count_out = 0;
-    if (stats_out) for (int k = 0; k < 4; ++k) stats_out[k] = 0;
-    if (n == 0) return SELHIP_OK;
-    for (int64_t i = 1; i < n; ++i)
-        if (h_cards[i] < h_cards[i - 1]) { set_err(nullptr, "cards are not in ascending order"); return SELHIP_E_BADARG; }
-    const int64_t B = std::min(block_genomes, n);
-    const int64_t nb = (n + B - 1) / B;
-    const size_t hb = (size_t)1 << p_hll, ab = need_aux_hll ? ((size_t)1 << p_aux) : 0;
-    std::vector<std::pair<int64_t, int64_t>> tiles;              // row-major: the resident row block changes rarely
-    for (int64_t I = 0; I < nb; ++I) for (int64_t J = I; J < nb; ++J) tiles.emplace_back(I, J);
-    const int W = (int)std::min<int64_t>(n_streams, (int64_t)tiles.size());
-    std::vector<OocWorker> ws((size_t)W);
-    std::vector<std::thread> th;
-    for (int w = 0; w < W; ++w) th.emplace_back([&, w] {
-        OocWorker& k = ws[(size_t)w];
-        auto fail = [&](int rc, const char* what) -> void { k.rc = rc; k.err = what ? what : ""; };
-        if (hipSetDevice(device) != hipSuccess) return fail(SELHIP_E_HIP, "hipSetDevice");
-        int r = selhip_ctx_create(&k.ctx, device);
-        if (r) return fail(r, selhip_last_error(nullptr));
-        hipStream_t st = nullptr;
-        if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) return fail(SELHIP_E_HIP, "hipStreamCreate");
-        r = selhip_ctx_set_stream(k.ctx, st);
-        if (!r) r = selhip_ctx_set_fp_mode(k.ctx, fp_mode);
-        if (r) return fail(r, selhip_last_error(k.ctx));
-        if (hipMalloc((void**)&k.d_hll, (size_t)2 * B * hb) != hipSuccess || hipMalloc((void**)&k.d_aux, (size_t)2 * B * m * 8) != hipSuccess ||
-            hipMalloc((void**)&k.d_cards, (size_t)2 * B * 8) != hipSuccess || (need_aux_hll && hipMalloc((void**)&k.d_aux_hll, (size_t)2 * B * ab) != hipSuccess))
-            return fail(SELHIP_E_HIP, "hipMalloc of the out-of-core driver's device buffers failed");
-        auto put = [&](int64_t blk, int64_t at) -> bool {         // block `blk` of the host arrays -> device rows [at, at + len)
-            const int64_t g0 = blk * B, len = std::min(B, n - g0);
-            bool ok = hipMemcpyAsync(k.d_hll + (size_t)at * hb, h_hll + (size_t)g0 * hb, (size_t)len * hb, hipMemcpyHostToDevice, st) == hipSuccess;
-            ok = ok && hipMemcpyAsync(k.d_aux + (size_t)at * m, h_aux + (size_t)g0 * m, (size_t)len * m * 8, hipMemcpyHostToDevice, st) == hipSuccess;
-            ok = ok && hipMemcpyAsync(k.d_cards + at, h_cards + g0, (size_t)len * 8, hipMemcpyHostToDevice, st) == hipSuccess;
-            if (need_aux_hll) ok = ok && hipMemcpyAsync(k.d_aux_hll + (size_t)at * ab, h_aux_hll + (size_t)g0 * ab, (size_t)len * ab, hipMemcpyHostToDevice, st) == hipSuccess;
-            return ok;
-        };
-        std::vector<selhip_pair_t> part;
-        for (size_t t = (size_t)w; t < tiles.size(); t += (size_t)W) {
-            const int64_t I = tiles[t].first, J = tiles[t].second;
-            const int64_t i0 = I * B, nI = std::min(B, n - i0), j0 = J * B, nJ = std::min(B, n - j0);
-            if (k.resident_i != I) { if (!put(I, 0)) return fail(SELHIP_E_HIP, "upload of a row block"); k.resident_i = I; }
-            const bool diag = I == J;
-            if (!diag && !put(J, nI)) return fail(SELHIP_E_HIP, "upload of a candidate block");
-            const int64_t tot = diag ? nI : nI + nJ;
-            r = selhip_ctx_attach(k.ctx, k.d_hll, (const uint64_t*)k.d_aux, k.d_cards, tot, m, p_hll);
-            if (!r && need_aux_hll) r = selhip_ctx_attach_aux_hll(k.ctx, k.d_aux_hll, p_aux);
-            if (!r) r = selhip_ctx_set_criterion(k.ctx, criterion);
-            if (!r) r = selhip_ctx_set_candidate_begin(k.ctx, diag ? 0 : nI);
-            if (!r) r = selhip_ctx_run(k.ctx, mode, algo, tau_f, n_rows, n_bands, 0, nI);
-            if (r) return fail(r, selhip_last_error(k.ctx));
-            const int64_t cnt = selhip_ctx_result_count(k.ctx);
-            part.resize((size_t)cnt);
-            int64_t s4[4];
-            r = selhip_ctx_fetch(k.ctx, cnt ? part.data() : nullptr, cnt);
-            if (!r) r = selhip_ctx_stats(k.ctx, s4);
-            if (r) return fail(r, selhip_last_error(k.ctx));
-            for (int q = 0; q < 4; ++q) k.stats[q] += s4[q];
-            for (auto& pr : part) {                               // local ranks -> global ranks
-                pr.i = (int32_t)(i0 + pr.i);
-                pr.k = (int32_t)(diag ? i0 + pr.k : j0 + (pr.k - nI));
-            }
-            k.out.insert(k.out.end(), part.begin(), part.end());
-        }
-        (void)hipStreamSynchronize(st);
-    });
-    for (auto& t : th) t.join();
-    int fail_rc = 0;
-    for (int w = 0; w < W; ++w) {
-        OocWorker& k = ws[(size_t)w];
-        if (k.rc && !fail_rc) { fail_rc = k.rc; set_err(nullptr, "out-of-core worker %d: %s", w, k.err.c_str()); }
-        (void)hipSetDevice(device);
-        hipStream_t st = k.ctx ? k.ctx->stream : nullptr;
-        if (k.ctx) selhip_ctx_destroy(k.ctx);
-        if (st) (void)hipStreamDestroy(st);
-        if (k.d_hll) (void)hipFree(k.d_hll);
-        if (k.d_aux) (void)hipFree(k.d_aux);
-        if (k.d_cards) (void)hipFree(k.d_cards);
-        if (k.d_aux_hll) (void)hipFree(k.d_aux_hll);
-    }
-    if (fail_rc) return fail_rc;
-    std::vector<selhip_pair_t> all;
-    for (auto& k : ws) { all.insert(all.end(), k.out.begin(), k.out.end()); if (stats_out) for (int q = 0; q < 4; ++q) stats_out[q] += k.stats[q]; }
-    std::sort(all.begin(), all.end(), [](const selhip_pair_t& a, const selhip_pair_t& b) { return a.i != b.i ? a.i < b.i : a.k < b.k; });
-    *count_out = (int64_t)all.size();
-    if (cap) std::memcpy(h_out, all.data(), (size_t)std::min<int64_t>((int64_t)all.size(), cap) * sizeof(selhip_pair_t));
-    if ((int64_t)all.size() > cap) { set_err(nullptr, "result buffer too small: %lld records", (long long)all.size()); return SELHIP_E_OVERFLOW; }
     return SELHIP_OK;
 }
 
-int selhip_multi_select(const int* devices, int n_devices,
-                        const uint8_t* h_hll, const uint64_t* h_aux, const double* h_cards,
-                        const uint8_t* h_aux_hll, int p_aux, int criterion,
-                        int64_t n, int m, int p_hll, int mode, int algo, int fp_mode, float tau_f, int n_rows, int n_bands,
-                        int gather, selhip_pair_t* h_out, int64_t cap, int64_t* count_out, int64_t stats_out[4]) {
-    if (!devices || n_devices < 1 || n_devices > 64 || !count_out || cap < 0 || (cap && !h_out)) { set_err(nullptr, "bad argument"); return SELHIP_E_BADARG; }
-    if (criterion < SELHIP_CRIT_SMH_A || criterion > SELHIP_CRIT_HLL_A_SMH_A) { set_err(nullptr, "bad criterion %d", criterion); return SELHIP_E_BADARG; }
-    if (criterion != SELHIP_CRIT_SMH_A && n > 0 && (!h_aux_hll || p_aux < 4 || p_aux > 16)) { set_err(nullptr, "criterion %d needs auxiliary HLL sketches (h_aux_hll, p_aux in [4,16])", criterion); return SELHIP_E_BADARG; }
-    if (gather < SELHIP_GATHER_HOST || gather > SELHIP_GATHER_RCCL_OR_HOST) { set_err(nullptr, "bad gather mode"); return SELHIP_E_BADARG; }
-    *count_out = 0;
-    const int G = n_devices;
-
-    // RCCL communicators (single process, one per device)
-    std::vector<void*> comms((size_t)G, nullptr);
-    bool use_rccl = gather != SELHIP_GATHER_HOST;
-    std::string rccl_note;
-    if (use_rccl) {
-        if (!g_rccl.load()) { use_rccl = false; rccl_note = "librccl.so not loadable"; }
-        else {
-            int r = g_rccl.CommInitAll(comms.data(), G, devices);
-            if (r != 0) { use_rccl = false; rccl_note = std::string("ncclCommInitAll: ") + g_rccl.GetErrorString(r); }
-        }
-        if (!use_rccl && gather == SELHIP_GATHER_RCCL) { set_err(nullptr, "RCCL gather requested but unavailable: %s", rccl_note.c_str()); return SELHIP_E_HIP; }
-    }
-
-    std::vector<selhip_ctx*> ctxs((size_t)G, nullptr);
-    std::vector<int> rc((size_t)G, 0);
-    std::vector<std::string> errs((size_t)G);
-    std::vector<std::vector<selhip_pair_t>> parts((size_t)G);
-    std::vector<int64_t> counts((size_t)G, 0);
-    std::vector<std::array<int64_t, 4>> st((size_t)G);
-    // phase 1: every device runs its shard
-    {
-        std::vector<std::thread> th;
-        for (int g = 0; g < G; ++g) th.emplace_back([&, g] {
-            int r = selhip_ctx_create(&ctxs[(size_t)g], devices[g]);
-            if (r) { rc[(size_t)g] = r; errs[(size_t)g] = selhip_last_error(nullptr); return; }
-            selhip_ctx* c = ctxs[(size_t)g];
-            r = selhip_ctx_set_fp_mode(c, fp_mode);
-            if (!r) r = selhip_ctx_upload(c, h_hll, h_aux, h_cards, n, m, p_hll);
-            if (!r && criterion != SELHIP_CRIT_SMH_A && n > 0) r = selhip_ctx_upload_aux_hll(c, h_aux_hll, p_aux);
-            if (!r) r = selhip_ctx_set_criterion(c, criterion);
-            // interleaved row blocks: every device gets the same share of pairs and of survivors
-            if (!r) r = selhip_ctx_set_row_interleave(c, 128, G, g);
-            if (!r) r = selhip_ctx_run(c, mode, algo, tau_f, n_rows, n_bands, 0, n);
-            if (!r) { counts[(size_t)g] = selhip_ctx_result_count(c); r = selhip_ctx_stats(c, st[(size_t)g].data()); }
-            if (r) { rc[(size_t)g] = r; errs[(size_t)g] = selhip_last_error(c); }
-        });
-        for (auto& t : th) t.join();
-    }
-    int fail = 0;
-    for (int g = 0; g < G; ++g) if (rc[(size_t)g]) { fail = rc[(size_t)g]; set_err(nullptr, "device %d: %s", devices[g], errs[(size_t)g].c_str()); }
-    std::vector<selhip_pair_t> all;
-    if (!fail) {
-        int64_t max_cnt = 0, total = 0;
-        for (int g = 0; g < G; ++g) { max_cnt = std::max(max_cnt, counts[(size_t)g]); total += counts[(size_t)g]; }
-        if (use_rccl) {
-            // phase 2: framed send buffers of (max_cnt + 1) records, one all_gather, device 0's copy goes to the host
-            const size_t frame = (size_t)(max_cnt + 1) * sizeof(selhip_pair_t);
-            std::vector<void*> send((size_t)G, nullptr), recv((size_t)G, nullptr);
-            std::vector<std::thread> th;
-            std::vector<char> host_recv;
-            for (int g = 0; g < G; ++g) th.emplace_back([&, g] {
-                selhip_ctx* c = ctxs[(size_t)g];
-                hipError_t e = hipSetDevice(devices[g]);
-                if (e == hipSuccess) e = hipMalloc(&send[(size_t)g], frame);
-                if (e == hipSuccess) e = hipMalloc(&recv[(size_t)g], frame * (size_t)G);
-                if (e == hipSuccess) e = hipMemsetAsync(send[(size_t)g], 0, frame, c->stream);
-                if (e != hipSuccess) { rc[(size_t)g] = SELHIP_E_HIP; errs[(size_t)g] = hipGetErrorString(e); return; }
-                int r = selhip_ctx_copy_results_framed(c, send[(size_t)g], max_cnt);
-                if (r) { rc[(size_t)g] = r; errs[(size_t)g] = selhip_last_error(c); return; }
-                int nr = g_rccl.AllGather(send[(size_t)g], recv[(size_t)g], frame, kNcclChar, comms[(size_t)g], c->stream);
-                if (nr != 0) { rc[(size_t)g] = SELHIP_E_HIP; errs[(size_t)g] = std::string("ncclAllGather: ") + g_rccl.GetErrorString(nr); return; }
-                e = hipStreamSynchronize(c->stream);
-                if (e != hipSuccess) { rc[(size_t)g] = SELHIP_E_HIP; errs[(size_t)g] = hipGetErrorString(e); }
-            });
-            for (auto& t : th) t.join();
-            for (int g = 0; g < G; ++g) if (rc[(size_t)g]) { fail = rc[(size_t)g]; set_err(nullptr, "gather on device %d: %s", devices[g], errs[(size_t)g].c_str()); }
-            if (!fail) {
-                host_recv.resize(frame * (size_t)G);
-                (void)hipSetDevice(devices[0]);
-                if (hipMemcpy(host_recv.data(), recv[0], host_recv.size(), hipMemcpyDeviceToHost) != hipSuccess) { fail = SELHIP_E_HIP; set_err(nullptr, "copy of the gathered records failed"); }
-                for (int g = 0; g < G && !fail; ++g) {
-                    const char* f = host_recv.data() + (size_t)g * frame;
-                    uint64_t cnt;
-                    std::memcpy(&cnt, f, 8);
-                    if ((int64_t)cnt != counts[(size_t)g]) { fail = SELHIP_E_HIP; set_err(nullptr, "gathered count mismatch on rank %d", g); break; }
-                    const selhip_pair_t* rec = reinterpret_cast<const selhip_pair_t*>(f + sizeof(selhip_pair_t));
-                    all.insert(all.end(), rec, rec + cnt);
-                }
-            }
-            for (int g = 0; g < G; ++g) { (void)hipSetDevice(devices[g]); if (send[(size_t)g]) (void)hipFree(send[(size_t)g]); if (recv[(size_t)g]) (void)hipFree(recv[(size_t)g]); }
-        } else {
-            for (int g = 0; g < G && !fail; ++g) {
-                parts[(size_t)g].resize((size_t)counts[(size_t)g]);
-                int r = selhip_ctx_fetch(ctxs[(size_t)g], parts[(size_t)g].data(), counts[(size_t)g]);
-                if (r) { fail = r; set_err(nullptr, "fetch on device %d: %s", devices[g], selhip_last_error(ctxs[(size_t)g])); }
-                all.insert(all.end(), parts[(size_t)g].begin(), parts[(size_t)g].end());
-            }
-        }
-        if (!fail) {
-            std::sort(all.begin(), all.end(), [](const selhip_pair_t& a, const selhip_pair_t& b) { return a.i != b.i ? a.i < b.i : a.k < b.k; });
-            *count_out = (int64_t)all.size();
-            std::memcpy(h_out, all.data(), (size_t)std::min<int64_t>((int64_t)all.size(), cap) * sizeof(selhip_pair_t));
-            if (stats_out) {
-                for (int k = 0; k < 4; ++k) { stats_out[k] = 0; for (int g = 0; g < G; ++g) stats_out[k] += st[(size_t)g][(size_t)k]; }
-            }
-            if ((int64_t)all.size() > cap) fail = SELHIP_E_OVERFLOW;
-            (void)total;
-        }
-    }
-    for (int g = 0; g < G; ++g) if (ctxs[(size_t)g]) selhip_ctx_destroy(ctxs[(size_t)g]);
-    if (use_rccl) for (int g = 0; g < G; ++g) if (comms[(size_t)g]) (void)g_rccl.CommDestroy(comms[(size_t)g]);
-    if (!fail && !rccl_note.empty()) set_err(nullptr, "note: host gather used (%s)", rccl_note.c_str());
-    return fail;
-}
+void* selhip_internal_stream(selhip_ctx* c) { return c ? (void*)c->stream : nullptr; }
 
 // ---- synthetic data ----------------------------------------------------------------------------
 int selhip_synth_generate(const selhip_synth_t* sp_in, int64_t g_begin, int64_t g_end,

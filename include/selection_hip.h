@@ -145,9 +145,16 @@ int selhip_ctx_set_candidate_begin(selhip_ctx* ctx, int64_t k_min);
  *   "join_bits"   16 (default): all-pairs join on 16-bit band signatures packed two per dword, its matches cut back to the
  *                 32-bit candidate set during verification; 15: the same with 15-bit signatures and flag arithmetic made of
  *                 plain VOP2 instructions only (LDS form); 32: join on the 32-bit signatures directly
+ *   "join_form"   inner loop of the 16-bit LDS-tile join: 0 (default) = v_xor_b32 + v_pk_min_u16; 1 = zero-half test, three 2-cycle
+ *                 instructions per packed dword (v_xor_b32, v_sub_u32, v_bitop3_b32; measured slower)
+ *   "join_tri"    1: the LDS-tile join launches only the (tile, candidate block) units above the diagonal (contiguous rows; measured:
+ *                 no gain); 0 (default): the rectangle, whose blocks under the diagonal leave at once
  *   "join_db"     1 (default) / 0: double-buffered query batches in the DPP form of the 16-bit join
  *   "join_wpb"    waves per block of the 16-bit join: LDS form 4 (default) or 8, DPP form 1 or 4
  *   "sig_tile"    1 (default): signature build 16 genomes per block with an LDS transpose; 0: one thread per bucket
+ *   "sig_cache"   1: the band signatures are kept across the passes of this context (they depend on the sketches and the band shape
+ *                 only; upload / attach drop them) -- for callers that run many passes over one set, e.g. every rank of a
+ *                 strong-scaled job; 0 (default): every pass builds them
  *   "hist_algo"   stage 2a: -1 (default) / 1 = on the registers' bit planes, written at upload / attach (hll_union_hist_bs_kernel:
  *                 bit-serial max, decode tree, population counts; p = 14 only); 0 = on the byte rows with a lane-private LDS
  *                 histogram (hll_union_hist_runs_kernel).  Takes effect at the next upload / attach.
@@ -156,10 +163,9 @@ int selhip_ctx_set_candidate_begin(selhip_ctx* ctx, int64_t k_min);
  *   "group_label" stage-2 grouping lays the query-row buckets out by label = a row's smallest partner, so that the pairs of a
  *                 cluster of similar genomes are neighbours in the list and their HLL rows stay in L2 (-1 = automatic: sets
  *                 whose HLL rows exceed 192 MiB and passes of >= 4e8 pairs; 0 off; 1 on);
- *   "hist_pad"    extra LDS bytes per stage-2a block (lowers the resident waves per CU; measurement knob)
- *   "verify_fb"   test hook: 1 sends every candidate through the hash-collision fallback of the verification
- *   "init_cap"    test hook: initial capacity of the candidate / survivor / result lists (they grow and the pass repeats)
- *   "enum_pairs"  test hook: pairs listed per sub-pass when hll_a / hll_an is the first criterion (default 2^26) */
+ *   "timed_kernel" see selhip_ctx_timing.
+ * (The library also answers to a few names that are NOT part of this interface -- hooks of its own test-suite and measurement
+ * knobs, listed at selhip_ctx_set_param in csrc/selection_kernels.hip.) */
 int selhip_ctx_set_param(selhip_ctx* ctx, const char* name, int value);
 /* what the context decided (read-only): "hll_khi" (largest p = 14 register value + 1; 0 = no bit planes), "hist_bitplanes",
  * "label_order", "join_tile_rows", "chunks" (chunk lanes of the last pass) */

@@ -243,6 +243,25 @@ def test_interleaved_row_blocks_tile_the_pair_space(oracle):
                         cat = cat[np.lexsort((cat["k"], cat["i"]))]
                         assert_same_pairs(cat, want)
                         assert ev == st["evaluated"], (crit, mode, algo, parts, ev, st)
+        # the multi-rank combination of ADVICE r2: row interleave + two chunk lanes + label-ordered grouping, every part (bit planes
+        # and byte rows)
+        for crit in (pkg.CRIT_SMH_A, pkg.CRIT_HLL_A_SMH_A):
+            sel.set_criterion(crit)
+            want, st = oracle.select(hll, aux, cards, cfg.tau, r, b, use_cb=False, criterion=crit, aux_hll=aux_hll, p_aux=8)
+            for lanes, label in ((2, 1), (3, 1), (2, 0)):
+                sel.set_pipeline(lanes); sel.set_param("group_label", label)
+                for parts, block in ((2, 64), (8, 32)):
+                    got, ev = [], 0
+                    for part in range(parts):
+                        sel.set_row_interleave(block, parts, part)
+                        got.append(sel.run(cfg.tau, MODE_SMH, r, b))
+                        ev += sel.stats()["evaluated"]
+                    sel.set_row_interleave(0, 1, 0)
+                    cat = np.concatenate(got)
+                    cat = cat[np.lexsort((cat["k"], cat["i"]))]
+                    assert_same_pairs(cat, want)
+                    assert ev == st["evaluated"]
+        sel.set_pipeline(-1); sel.set_param("group_label", -1)
         # a sub-range of rows combined with the interleave
         sel.set_criterion(pkg.CRIT_SMH_A)
         want, _ = oracle.select(hll, aux, cards, cfg.tau, r, b)
@@ -306,6 +325,24 @@ def test_join_and_histogram_variants(oracle):
                 assert s["candidates"] == cand          # the 32-bit candidate set is the same whichever join produced it
             sel.set_param("join_bits", 16); sel.set_param("join_db", 1); sel.set_param("verify_fb", 0); sel.set_param("join_wpb", 4)
             sel.set_param("join_q", 1); sel.set_param("join_qt", 0)
+            # inner loop of the LDS-tile join: zero-half test (default) vs packed minimum -- same 16-bit matches, hence the same candidates
+            for form, wpb, qt in ((0, 4, 32), (1, 8, 64), (0, 8, 128), (1, 4, 0)):
+                sel.set_param("join_form", form); sel.set_param("join_wpb", wpb); sel.set_param("join_qt", qt)
+                assert_same_pairs(sel.run(tau, MODE_CB_SMH, r, b, algo=ALGO_SIG), want)
+                s = sel.stats()
+                assert s["evaluated"] == st["evaluated"] and s["survivors"] == st["survivors"] and s["candidates"] == cand
+                assert_same_pairs(sel.run(tau, MODE_SMH, r, b, algo=ALGO_SIG), want_all)
+            sel.set_param("join_form", 0); sel.set_param("join_wpb", 4); sel.set_param("join_qt", 0)
+            # grid of the LDS-tile join: only the units above the diagonal (default) vs the whole rectangle, whole set and row ranges
+            for tri, qt in ((0, 32), (1, 16), (1, 64), (0, 128), (1, 128), (1, 0)):
+                sel.set_param("join_tri", tri); sel.set_param("join_qt", qt)
+                assert_same_pairs(sel.run(tau, MODE_CB_SMH, r, b, algo=ALGO_SIG), want)
+                assert sel.stats()["evaluated"] == st["evaluated"]
+                assert_same_pairs(sel.run(tau, MODE_SMH, r, b, algo=ALGO_SIG), want_all)
+                for lo, hi_ in ((64, 200), (96, 97), (0, 33), (128, want_all["i"].max() + 2)):
+                    hi_ = min(int(hi_), hll.shape[0])
+                    assert_same_pairs(sel.run(tau, MODE_SMH, r, b, rows=(lo, hi_), algo=ALGO_SIG), want_all[(want_all["i"] >= lo) & (want_all["i"] < hi_)])
+            sel.set_param("join_tri", 0); sel.set_param("join_qt", 0)
             for run, blocks, label in ((1, 8, 0), (3, 64, 1), (8, 2048, 0), (1024, 16384, 1), (1, 16384, 0), (0, 16384, 1), (0, 16384, -1)):
                 sel.set_param("hist_run", run); sel.set_param("hist_blocks", blocks); sel.set_param("group_label", label)
                 assert_same_pairs(sel.run(tau, MODE_CB_SMH, r, b), want)
@@ -516,6 +553,47 @@ def test_building_blocks(oracle):
         assert bool(flags[j]) == oracle.smh_a(aux[pairs[j, 0]], aux[pairs[j, 1]], r, b)
         assert mc[j] == int((aux[pairs[j, 0]] == aux[pairs[j, 1]]).sum())
     assert flags.sum() > 0
+
+
+def test_aux_precision_limit_and_counter_recovery(oracle):
+    """(1) the auxiliary criteria count in 16-bit bins, so p_aux = 15 is the largest precision any entry point takes -- a
+    pair of EMPTY auxiliary sketches (one bin holding all 32 768 registers) must still give the oracle's answer there, and 16 is
+    refused; (2) an enqueue that fails after it claimed its counter set must not leave stale counters for the passes behind it"""
+    cfg = SynthConfig("paux", 60, 128, 0.9, 0x77, p_aux=8, n_sh_lo=6000, n_sh_hi=6000)
+    hll, aux, cards, _, _ = sorted_set(cfg, oracle)
+    n = hll.shape[0]
+    rng = np.random.default_rng(4)
+    for p_aux in (15, 12):
+        ah = np.minimum(rng.geometric(0.5, size=(n, 1 << p_aux)), 40).astype(np.uint8)
+        ah[0] = 0; ah[1] = 0                          # two empty sketches: union histogram = one bin of 2^p_aux
+        ah[2] = 7; ah[3] = 7                          # ... and two constant ones
+        ah[5] = ah[4]
+        r, b = pkg.banding(cfg.m, 0.5)
+        with Selector(0) as sel:
+            sel.upload(hll, aux, cards)
+            sel.upload_aux_hll(ah, p_aux)
+            for crit in (pkg.CRIT_HLL_A, pkg.CRIT_HLL_AN, pkg.CRIT_HLL_A_SMH_A):
+                sel.set_criterion(crit)
+                want, st = oracle.select(hll, aux, cards, 0.5, r, b, use_cb=False, criterion=crit, aux_hll=ah, p_aux=p_aux)
+                assert_same_pairs(sel.run(0.5, MODE_SMH, r, b), want)
+                assert sel.stats()["survivors"] == st["survivors"]
+            with pytest.raises(pkg.SelhipError):
+                sel.upload_aux_hll(np.zeros((n, 1 << 16), dtype=np.uint8), 16)
+    cfg = make_golden.GOLDEN_SYNTH["synth_flat_n300_m512"]
+    hll, aux, cards, _, _ = sorted_set(cfg, oracle)
+    r, b = pkg.banding(cfg.m, 0.5)
+    want, st = oracle.select(hll, aux, cards, 0.5, r, b)
+    with Selector(0) as sel:
+        sel.upload(hll, aux, cards)
+        for _ in range(3):
+            assert_same_pairs(sel.run(0.5, MODE_CB_SMH, r, b), want)
+            sel.set_param("fail_after_flip", 1)
+            with pytest.raises(pkg.SelhipError):
+                sel.run(0.5, MODE_CB_SMH, r, b)
+            for _ in range(2):                        # the pass after the failure, and the one after that (which uses the other set)
+                assert_same_pairs(sel.run(0.5, MODE_CB_SMH, r, b), want)
+                s = sel.stats()
+                assert s["evaluated"] == st["evaluated"] and s["survivors"] == st["survivors"] and s["selected"] == len(want)
 
 
 def test_bitplane_histograms(oracle):
@@ -844,3 +922,25 @@ def test_multi_device_entry_and_rccl_gather(oracle):
         multi_select([0, 0], hll, aux, cards, cfg.tau, MODE_CB_SMH, r, b, gather=1)      # RCCL required, duplicate GPU
     with pytest.raises(pkg.SelhipError):
         multi_select([7], hll, aux, cards, cfg.tau, MODE_CB_SMH, r, b, gather=0)         # no such device
+    # RCCL with the replicas completed by an in-place all-gather (one rank here: its slice is the whole set), every criterion
+    for crit in (pkg.CRIT_HLL_A, pkg.CRIT_HLL_A_SMH_A):
+        want_c, _ = oracle.select(hllx, auxx, cardsx, cfgx.tau, rx, bx, criterion=crit, aux_hll=ahx, p_aux=8)
+        got, _ = multi_select([0], hllx, auxx, cardsx, cfgx.tau, MODE_CB_SMH, rx, bx, gather=1, criterion=crit, aux_hll=ahx, p_aux=8)
+        assert_same_pairs(got, want_c)
+    # a device thread that fails -- before the replica all-gather, before its pass, before the gather of the records -- must end the
+    # call with an error, never leave the other threads waiting in a collective (no ncclCommAbort was bound)
+    import os
+    for devices, gather in (([0], 1), ([0, 0, 0], 0)):
+        for stage in ("upload", "run", "gather"):
+            os.environ["SELHIP_TEST_FAIL"] = f"{len(devices) - 1}:{stage}"
+            try:
+                with pytest.raises(pkg.SelhipError, match="test hook"):
+                    multi_select(devices, hll, aux, cards, cfg.tau, MODE_CB_SMH, r, b, gather=gather)
+            finally:
+                del os.environ["SELHIP_TEST_FAIL"]
+            got, _ = multi_select(devices, hll, aux, cards, cfg.tau, MODE_CB_SMH, r, b, gather=gather)      # and the next call is fine
+            assert_same_pairs(got, want)
+    unsorted = cards.copy(); unsorted[[3, 4]] = unsorted[[4, 3]]
+    if unsorted[3] != unsorted[4]:
+        with pytest.raises(pkg.SelhipError, match="ascending"):
+            multi_select([0], hll, aux, unsorted, cfg.tau, MODE_CB_SMH, r, b, gather=1)
