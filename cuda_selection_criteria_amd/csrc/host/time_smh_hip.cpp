@@ -2,15 +2,21 @@
 // Prints the same `list;label;tau;seconds` records (parsed by run_time_experiment.sh:24-26,37-39) for
 // the two timed regions "smh_a" (all pairs) and "CB+smh_a", but (a) the device is synchronised before
 // the clock stops (the reference stops it right after an asynchronous launch, time_smh_cuda.cpp:279-283),
-// and (b) sketches are either loaded from disk (-l, .hll + .smh<m> files) or synthesised on the GPU
-// (-N genomes; stands in for rebuilding SuperMinHash from FASTA, time_smh_cuda.cpp:181-211).
-//   -l list | -N n_genomes   -h tau   -m buckets   -b block(ignored)   -R repetitions   -S seed   -A algo
+// and (b) the sketches come from one of three places:
+//   -l list          like the reference (time_smh_cuda.cpp:181-211): every entry's <file>.hll is read from disk and its
+//                    SuperMinHash is REBUILT from the FASTA <file> -- on the GPU (selhip_build_sketches); that is the
+//                    timed "build_smh" record;
+//   -l list -D       .hll and .smh<m> both loaded from disk (no FASTA needed);
+//   -N n_genomes     synthesised on the GPU.
+//   -l list [-D] | -N n_genomes   -h tau   -m buckets   -b block(ignored)   -R repetitions   -S seed   -A algo
 #include <unistd.h>
 
+#include <algorithm>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <fstream>
 #include <iostream>
 #include <string>
 #include <vector>
@@ -22,17 +28,30 @@ static double now_s() {
     return std::chrono::duration<double>(std::chrono::high_resolution_clock::now().time_since_epoch()).count();
 }
 
+static void load_file_list(std::vector<std::string>& files, const std::string& list_file) {   // time_smh_cuda.cpp:101-123
+    std::ifstream file(list_file);
+    if (!file.is_open()) { std::cerr << "No valid input file provided\n"; exit(-1); }
+    std::string line;
+    while (getline(file, line)) {
+        line.erase(0, line.find_first_not_of(" \t\r\n"));
+        line.erase(line.find_last_not_of(" \t\r\n") + 1);
+        if (!line.empty()) files.push_back(line);
+    }
+}
+
 int main(int argc, char* argv[]) {
     std::string list_file = "";
+    bool from_disk = false;
     float threshold = 0.9f;
     int mh_size = 8, total_rep = 1, algo = SELHIP_ALGO_AUTO;
     long n_synth = 0;
     unsigned long long seed = 0x5EED0000ull;
     int c;
-    while ((c = getopt(argc, argv, "xl:h:m:b:R:N:S:A:")) != -1) {
+    while ((c = getopt(argc, argv, "xDl:h:m:b:R:N:S:A:")) != -1) {
         switch (c) {
-            case 'x': std::cout << "Usage: -l list | -N genomes, -h tau -m buckets [-b block] [-R reps] [-S seed] [-A auto|stream|sig]\n"; return 0;
+            case 'x': std::cout << "Usage: -l list [-D: .smh files from disk instead of rebuilding from FASTA] | -N genomes, -h tau -m buckets [-b block] [-R reps] [-S seed] [-A auto|stream|sig]\n"; return 0;
             case 'l': list_file = optarg; break;
+            case 'D': from_disk = true; break;
             case 'h': threshold = std::stof(optarg); break;
             case 'm': mh_size = std::stoi(optarg); break;
             case 'b': break;
@@ -72,6 +91,58 @@ int main(int argc, char* argv[]) {
         if (!rc) rc = selhip_permute_rows(d_aux, d_aux_s, (const int32_t*)d_perm, n, (int64_t)mh_size * 8, nullptr);
         if (!rc) rc = selhip_ctx_attach(ctx, (const uint8_t*)d_hll_s, (const uint64_t*)d_aux_s, (const double*)d_cards_s, n, mh_size, 14);
         if (rc) { std::cerr << "setup failed: " << selhip_last_error(ctx) << "\n"; return 4; }
+    } else if (!from_disk) {
+        // time_smh_cuda.cpp:181-211: .hll from disk, SuperMinHash rebuilt from the FASTA -- here every k-mer of every genome on the GPU
+        std::vector<std::string> files;
+        load_file_list(files, list_file);
+        n = (int64_t)files.size();
+        const uint32_t m_vec = selhost_smh_vecsize((uint32_t)mh_size);             // SuperMinHash<>(mh_size) holds this many buckets (policy.h:12-19)
+        mh_size = (int)m_vec;
+        std::vector<uint8_t> hll((size_t)n * 16384);
+        std::vector<double> cards((size_t)n);
+        std::vector<int64_t> offsets{0};
+        for (int64_t g = 0; g < n; ++g) {
+            uint32_t p = 0, hdr[4]; double val = 0;
+            if (selhost_read_hll((files[(size_t)g] + ".hll").c_str(), hll.data() + (size_t)g * 16384, 16384, &p, hdr, &val) || p != 14) {
+                std::cerr << "Error opening file: " << files[(size_t)g] << ".hll (" << selhost_last_error() << ")\n"; return 4;
+            }
+            cards[(size_t)g] = selhost_hll_report(hll.data() + (size_t)g * 16384, 14, 1);
+            const int64_t len = selhost_fasta_codes(files[(size_t)g].c_str(), nullptr, 0);
+            if (len < 0) { std::cerr << "ERROR: Could not open the file " << files[(size_t)g] << " (" << selhost_last_error() << "); -D loads .smh files instead\n"; return 4; }
+            offsets.push_back(offsets.back() + len);
+        }
+        std::vector<uint8_t> flat((size_t)std::max<int64_t>(offsets.back(), 1));
+#pragma omp parallel for schedule(dynamic)
+        for (int64_t g = 0; g < n; ++g)
+            if (offsets[(size_t)g + 1] > offsets[(size_t)g]) selhost_fasta_codes(files[(size_t)g].c_str(), flat.data() + offsets[(size_t)g], (size_t)(offsets[(size_t)g + 1] - offsets[(size_t)g]));
+        std::vector<int32_t> perm((size_t)n);
+        std::vector<double> cards_s((size_t)n);
+        std::vector<uint8_t> hll_s((size_t)n * 16384);
+        int rc = selhost_sort_by_card(cards.data(), n, perm.data());                // time_smh_cuda.cpp:215
+        for (int64_t r = 0; r < n && !rc; ++r) {
+            cards_s[(size_t)r] = cards[(size_t)perm[(size_t)r]];
+            std::memcpy(hll_s.data() + (size_t)r * 16384, hll.data() + (size_t)perm[(size_t)r] * 16384, 16384);
+        }
+        void *d_codes = nullptr, *d_off = nullptr;
+        if (!rc) rc = selhip_malloc(&d_codes, flat.size());
+        if (!rc) rc = selhip_malloc(&d_off, offsets.size() * 8);
+        if (!rc) rc = selhip_malloc(&d_hll, (size_t)std::max<int64_t>(n, 1) * 16384);         // the builder's own HLL output (not used: the .hll files are)
+        if (!rc) rc = selhip_malloc(&d_aux, (size_t)std::max<int64_t>(n, 1) * m_vec * 8);
+        if (!rc) rc = selhip_malloc(&d_hll_s, (size_t)std::max<int64_t>(n, 1) * 16384);
+        if (!rc) rc = selhip_malloc(&d_aux_s, (size_t)std::max<int64_t>(n, 1) * m_vec * 8);
+        if (!rc) rc = selhip_malloc(&d_perm, (size_t)std::max<int64_t>(n, 1) * 4);
+        if (!rc) rc = selhip_malloc(&d_cards_s, (size_t)std::max<int64_t>(n, 1) * 8);
+        if (!rc) rc = selhip_memcpy_h2d(d_codes, flat.data(), flat.size());
+        if (!rc) rc = selhip_memcpy_h2d(d_off, offsets.data(), offsets.size() * 8);
+        if (!rc && n) rc = selhip_build_sketches((const uint8_t*)d_codes, (const int64_t*)d_off, n, 31, (int)m_vec, 0, (uint8_t*)d_hll, (uint64_t*)d_aux, nullptr, nullptr);
+        if (!rc) rc = selhip_memcpy_h2d(d_perm, perm.data(), (size_t)n * 4);
+        if (!rc) rc = selhip_memcpy_h2d(d_cards_s, cards_s.data(), (size_t)n * 8);
+        if (!rc) rc = selhip_memcpy_h2d(d_hll_s, hll_s.data(), hll_s.size());
+        if (!rc && n) rc = selhip_permute_rows(d_aux, d_aux_s, (const int32_t*)d_perm, n, (int64_t)m_vec * 8, nullptr);
+        if (!rc) rc = selhip_device_synchronize();
+        selhip_free(d_codes); selhip_free(d_off);
+        if (!rc) rc = selhip_ctx_attach(ctx, (const uint8_t*)d_hll_s, (const uint64_t*)d_aux_s, (const double*)d_cards_s, n, (int)m_vec, 14);
+        if (rc) { std::cerr << "setup failed: " << selhip_last_error(ctx) << " / " << selhip_last_error(nullptr) << "\n"; return 4; }
     } else {
         if (selhost_dataset_load(&ds, list_file.c_str(), (unsigned)mh_size, 0, 1, 8)) { std::cerr << selhost_last_error() << "\n"; exit(-1); }
         n = selhost_dataset_size(ds);

@@ -186,7 +186,7 @@ struct selhip_ctx {
     int sig_tile = 1;                   // signature build: tiled form (0 = one thread per bucket, the round-1 kernel)
     int init_cap = 0;                   // test hook: initial capacity of the survivor / candidate lists (0 = sized from the workload)
     int join_qt = 0;                    // query rows per signature-join block (multiple of 16); 0 = automatic: 32 rows below 1e8 pairs per pass, 64 up to 4.5e8
-                                        // (30 000 genomes on one GPU), 128 beyond.  With the segmented appends: cfg3 112 / 114 / 127 us at 64 / 96 / 128 rows (finer tiles balance
+                                        // (30 000 genomes on one GPU; 2e8 since round 3), 128 beyond.  With the segmented appends: cfg3 112 / 114 / 127 us at 64 / 96 / 128 rows (finer tiles balance
                                         // the 1 024 SIMDs better), cfg4 2.12 / 2.10 / 2.07 ms (a block's prologue -- 32 candidate loads per lane,
                                         // tile staging -- is amortised over more rows), cfg5 8.31 / 8.16 / 8.20 ms
     bool group_stage2 = true;           // bucket survivors by query row before stage 2a (hll_union_hist_runs_kernel)
@@ -354,7 +354,7 @@ unsigned grid_for(u64 items, unsigned per_block, unsigned max_blocks);
 int join_tile_rows(const selhip_ctx* c) {
     const double pairs_here = 0.5 * (double)c->n * (double)c->n / std::max(1, c->il_parts);       // this context's share of the triangle
     // (< 1e8 pairs: 32-row tiles -- twice the work units for the 8 192 wave slots, a shorter tail: cfg3's join 108.5 -> 104.3 us)
-    int qt = c->join_qt > 0 ? c->join_qt : (pairs_here >= 4.5e8 ? 128 : pairs_here >= 1e8 ? 64 : 32);
+    int qt = c->join_qt > 0 ? c->join_qt : (pairs_here >= 4.5e8 ? 128 : pairs_here >= 2e8 ? 64 : 32);      // (one of 8 ranks of cfg4, 1.6e8 pairs: 32 rows 0.450 ms, 64 rows 0.481)
     if (c->il_parts > 1) { qt = std::min(qt, c->il_block); while (c->il_block % qt) qt -= 16; }
     return qt;
 }

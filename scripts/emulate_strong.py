@@ -7,8 +7,10 @@ ROOT = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT))
 import torch
 import cuda_selection_criteria_amd as pkg
-wl = sys.argv[1] if len(sys.argv) > 1 else "cfg4"
-worlds = [int(x) for x in sys.argv[2:]] or [2, 4, 8]
+args = [a for a in sys.argv[1:] if not a.startswith("--")]
+flags = [a for a in sys.argv[1:] if a.startswith("--")]
+wl = args[0] if args else "cfg4"
+worlds = [int(x) for x in args[1:]] or [2, 4, 8]
 cfg = pkg.SYNTH_CONFIGS[wl]
 hll, aux, cards, _, ah = pkg.synth_device(cfg)
 r, b = pkg.banding(cfg.m, cfg.tau)
@@ -16,7 +18,16 @@ sel = pkg.Selector(0); sel.attach(hll, aux, cards)
 if cfg.p_aux:
     sel.attach_aux_hll(ah, cfg.p_aux); sel.set_criterion(pkg.CRIT_HLL_A_SMH_A)
 n = cfg.n_genomes
-def timeit(k=10):
+if "--sig-cache" in flags:
+    sel.set_param("sig_cache", 1)          # every rank of a strong-scaled job runs many passes over the same replica: signatures built once
+    print(wl, "signature cache ON (selhip_ctx_set_param sig_cache=1)", flush=True)
+for f in flags:
+    if f.startswith("--param="):
+        name, _, val = f[len("--param="):].partition("=")
+        sel.set_param(name, int(val)); print(wl, "param", name, "=", val, flush=True)
+    if f.startswith("--pipeline="):
+        sel.set_pipeline(int(f.split("=")[1])); print(wl, "pipeline", f.split("=")[1], flush=True)
+def timeit(k=20):
     for _ in range(2): sel.run(cfg.tau, pkg.MODE_SMH, r, b, fetch=False)
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for _ in range(k): sel.run(cfg.tau, pkg.MODE_SMH, r, b, fetch=False)

@@ -77,7 +77,7 @@ def timing(args):
         for rep in range(1, args.R + 1):
             # ---- gpu: bin/time_smh_hip prints list;label;tau;seconds
             cmd = [str(BIN / "time_smh_hip"), "-h", args.tau, "-m", str(m), "-b", "256"]
-            cmd += ["-l", args.l] if args.l else ["-N", str(args.N)]
+            cmd += ["-l", args.l, "-D"] if args.l else ["-N", str(args.N)]       # -D: sketch files from disk (the CPU side below loads the same files)
             out = subprocess.run(cmd, capture_output=True, text=True, check=True).stdout
             for ln in out.splitlines():
                 f = ln.split(";")

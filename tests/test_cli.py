@@ -47,7 +47,7 @@ def test_selection_cli_hll_criteria(crit):
 
 @pytest.mark.gpu
 def test_time_smh_hip_records():
-    out = subprocess.run([str(BIN / "time_smh_hip"), "-l", "influenza_filelist.txt", "-h", "0.9", "-m", "256", "-b", "256"],
+    out = subprocess.run([str(BIN / "time_smh_hip"), "-l", "influenza_filelist.txt", "-D", "-h", "0.9", "-m", "256", "-b", "256"],
                          cwd=GOLDEN, capture_output=True, text=True)
     assert out.returncode == 0, out.stderr
     lines = out.stdout.strip().splitlines()
@@ -57,6 +57,33 @@ def test_time_smh_hip_records():
     out = subprocess.run([str(BIN / "time_smh_hip"), "-N", "2000", "-h", "0.9", "-m", "256"], capture_output=True, text=True)
     assert out.returncode == 0, out.stderr
     assert "synthetic_N2000;smh_a;0.9;" in out.stdout and "pairs:1999000;" in out.stdout
+
+
+@pytest.mark.gpu
+def test_time_smh_hip_rebuilds_superminhash_from_fasta(tmp_path):
+    """`time_smh_hip -l` as experiments/src/time_smh_cuda.cpp:181-211 does it: .hll from disk, SuperMinHash rebuilt from the FASTA
+    (on the GPU).  The influenza genomes, FASTA and .hll side by side as the reference expects; the rebuilt sketches must select
+    what the .smh files on disk select (same record counts as the -D run) -- for m = 256 and for an m that is rounded up (100 -> 128)"""
+    import shutil
+    names = []
+    for f in sorted((GOLDEN / "influenza_fasta").glob("*.fna.gz")):
+        shutil.copy(f, tmp_path / f.name)
+        shutil.copy(GOLDEN / "influenza" / (f.name + ".hll"), tmp_path / (f.name + ".hll"))
+        names.append(f.name)
+    (tmp_path / "list.txt").write_text("\n".join(names) + "\n")
+    disk = subprocess.run([str(BIN / "time_smh_hip"), "-l", "influenza_filelist.txt", "-D", "-h", "0.01", "-m", "256"], cwd=GOLDEN, capture_output=True, text=True)
+    assert disk.returncode == 0, disk.stderr
+    out = subprocess.run([str(BIN / "time_smh_hip"), "-l", "list.txt", "-h", "0.01", "-m", "256"], cwd=tmp_path, capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+    lines, dlines = out.stdout.strip().splitlines(), disk.stdout.strip().splitlines()
+    assert [l.split(";")[1] for l in lines] == ["build_smh", "smh_a", "CB+smh_a"]
+    for a, b in zip(lines[1:], dlines[1:]):           # same banding, pairs, survivors, selected as with the files the reference wrote
+        assert a.split(";")[4:8] == b.split(";")[4:8], (a, b)
+    out = subprocess.run([str(BIN / "time_smh_hip"), "-l", "list.txt", "-h", "0.5", "-m", "100"], cwd=tmp_path, capture_output=True, text=True)
+    assert out.returncode == 0 and ";r:" in out.stdout and "pairs:45;" in out.stdout, out.stderr
+    (tmp_path / "bad.txt").write_text("no_such_genome.fna\n")
+    out = subprocess.run([str(BIN / "time_smh_hip"), "-l", "bad.txt", "-h", "0.5", "-m", "64"], cwd=tmp_path, capture_output=True, text=True)
+    assert out.returncode != 0
 
 
 @pytest.mark.gpu
