@@ -265,4 +265,12 @@ void hll_union_hist_bs_kernel(const uint32_t* __restrict__ bs, const uint8_t* __
     }
 }
 
+// (Round 3 also built this kernel with the NEXT pair's candidate planes prefetched through LDS -- every wave a slot of NB x 2 KiB filled by
+// LDS-DMA (`global_load_lds_dwordx4`) while the current pair is decoded, pair records and maxima read two pairs ahead; bit-identical in
+// the parity suite.  It changed nothing: cfg3 53.7 -> 56.6 us, hard 0.874 -> 0.878 ms, cfg4 / cfg5 equal (gpurun_out/r03/g_pf*).  The PMC
+// pass says why (profiles/r03b_pmc_summary.json): the vector units are ACTIVE for 0.71 of the kernel at cfg3 and 0.83 on the hard set --
+// ~4.1 cycles per instruction: in this mix of dependent chains the boolean instructions do not reach the 2.2 cycles they show alone --
+// so the waves are not waiting for memory, they are waiting for each other's arithmetic.  Dropped; what is left to gain here is
+// instruction count.)
+
 }  // namespace

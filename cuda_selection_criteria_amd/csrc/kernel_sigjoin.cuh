@@ -719,6 +719,12 @@ void verify_kernel(const u64* __restrict__ aux, int m, int n_rows, int n_bands,
     }
 }
 
+// (Round 3 built and measured the alternative of verifying INSIDE the join: every wave of sigl_join_kernel checked its own 16-bit matches
+// at its end -- the candidate registers are free there -- and a light kernel compacted the survivors; bit-identical in all 90 parity tests.
+// It lost: cfg3 join 101 -> 128 us for a verification 25 -> 7 us (step 0.250 -> 0.261 ms), cfg2 join 12.5 -> 26.5 us, cfg4 even
+// (gpurun_out/r03/f_jv*).  A wave meets ~8 matches, so its own verification is two or three dependent memory round trips for a
+// handful of pairs -- 6-8 us added to a 45 us wave that holds one of the 8 192 slots the second round of waves is waiting for -- and
+// keeping the row loop at 64 registers beside it cost spills.  The separate kernel stays.)
 // verify16_kernel: verification behind the 16-bit join.  A wave takes 64 pairs of the join's output at a time and works
 // on them four at a time, 16 lanes per pair (step s: quarter-wave q has pair 4s+q).
 //  1. 32-bit signatures: the lanes of a quarter read the two genomes' signature rows from the genome-major copy sigQ

@@ -604,7 +604,7 @@ def test_bitplane_histograms(oracle):
     lib = pkg.hip_lib()
     dev = torch.device("cuda", 0)
     rng = np.random.default_rng(11)
-    for vmax in (3, 15, 16, 23, 24, 31, 32, 47, 51, 63):
+    for vmax in (3, 14, 15, 16, 23, 24, 31, 32, 47, 51, 63):
         n = 40
         hll = rng.integers(0, vmax + 1, size=(n, 16384), dtype=np.uint8)
         hll[0] = 0                                   # empty sketch
@@ -644,10 +644,11 @@ def test_bitplane_histograms(oracle):
         for algo in (0, 1, -1):
             sel.set_param("hist_algo", algo)
             sel.upload(hll, aux, cards)
-            for run, blocks, label in ((1, 8, 0), (3, 64, 1), (0, 2048, -1)):
+            for run, blocks, label in ((1, 8, 0), (3, 64, 1), (5, 16, 1), (0, 2048, -1)):
                 sel.set_param("hist_run", run); sel.set_param("hist_bs_blocks", blocks); sel.set_param("group_label", label)
                 assert_same_pairs(sel.run(0.5, MODE_CB_SMH, r, b), want)
                 assert sel.stats()["survivors"] == st["survivors"]
+                assert_same_pairs(sel.run(0.5, MODE_CB_SMH, r, b, rows=(17, 333)), want[(want["i"] >= 17) & (want["i"] < 333)])
         with pytest.raises(pkg.SelhipError):
             sel.set_param("hist_algo", 2)
 
