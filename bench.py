@@ -511,17 +511,28 @@ def main():
                                                       f"{times[0]:.2f} s and {times[1]:.2f} s wall, difference = {dp} pairs (CB+smh_a mode, the program's only mode)"}
             except Exception as e:                     # the reference binary is optional equipment
                 out["cpu_reference"] = {"error": str(e)[:200]}
-    if rank == 0 and world == 1 and args.pcie:
-        # PCIe-inclusive variant (never `value`): host buffers handed to selhip_ctx_upload, then one pass
+    if rank == 0 and world == 1 and (args.pcie or not args.no_extras):
+        # PCIe-inclusive variant (never `value`): the boundary handed HOST buffers (selhip_ctx_upload: copies, bit planes of the HLL
+        # registers, cardinalities given), then one pass.  First call = with the context's allocations; second = the same context again.
         h = hll_t.cpu().numpy(); a = aux_t.cpu().numpy().view(np.uint64)
+        nbytes = int(h.nbytes + a.nbytes + cards.nbytes)
         with pkg.Selector(local_rank) as s2:
-            t = time.perf_counter()
-            s2.upload(h, a, cards)
-            s2.run(cfg.tau, mode, n_rows, n_bands, algo=algo, fetch=False)
-            dt2 = time.perf_counter() - t
+            times = []
+            for _ in range(3):
+                torch.cuda.synchronize(dev)
+                t = time.perf_counter()
+                s2.upload(h, a, cards)
+                t_up = time.perf_counter() - t
+                s2.run(cfg.tau, mode, n_rows, n_bands, algo=algo, fetch=False)
+                times.append((time.perf_counter() - t, t_up))
             ev2 = s2.stats()["evaluated"]
-        out["pcie_inclusive"] = {"pairs_per_s": ev2 / dt2, "seconds": dt2, "bytes_uploaded": int(h.nbytes + a.nbytes + cards.nbytes),
-                                 "note": "pageable host buffers -> selhip_ctx_upload -> one pass; not the headline"}
+        best = min(times[1:])
+        out["pcie_inclusive"] = {"pairs_per_s": ev2 / best[0], "seconds": best[0], "upload_seconds": best[1], "first_call_seconds": times[0][0],
+                                 "bytes_uploaded": nbytes, "upload_GBs": nbytes / best[1] / 1e9,
+                                 "note": "pageable host buffers -> selhip_ctx_upload (copies + bit planes) -> one pass; best of two calls on a warm context, "
+                                         "first_call_seconds includes the context's allocations.  Never the headline.  The link moves 54-56 GB/s from pageable "
+                                         "and pinned memory alike (scripts/pcie_probe.py), so these bytes cannot arrive in less than "
+                                         f"{nbytes / 55e9 * 1e3:.1f} ms"}
     if rank == 0:
         print(json.dumps(out), flush=True)
     sel.close()
