@@ -143,6 +143,7 @@ struct selhip_ctx {
                                         // the 1 024 SIMDs better), cfg4 2.12 / 2.10 / 2.07 ms (a block's prologue -- 32 candidate loads per lane,
                                         // tile staging -- is amortised over more rows), cfg5 8.31 / 8.16 / 8.20 ms
     bool group_stage2 = true;           // bucket survivors by query row before stage 2a (hll_union_hist_runs_kernel)
+    int group_min_n = 2048;             // ... for sets of more than this many genomes ("group_min_n"; see grouping_on)
 
     // last run parameters (for overflow re-runs)
     bool have_run = false, pending = false;
@@ -231,6 +232,11 @@ double relerr_scaled_for(int p) {
     // hll.h:662  relerr /= std::sqrt(m), relerr = 1e-2 (hll.h:211 default, :257)
     return 1e-2 / std::sqrt((double)(1ull << p));
 }
+
+// stage 2 works on a list bucketed by query row (and laid out by label) unless the caller switched that off -- or the set is small:
+// up to group_min_n genomes (2 048) the whole table of bit planes (<= 20 MB) stays in L2 / the Infinity Cache whatever the order, and
+// the two grouping launches are 13 us of a 95 us step (BASELINE configs[1])
+bool grouping_on(const selhip_ctx* c) { return c->p == 14 && c->group_stage2 && c->n > c->group_min_n; }
 
 bool is_pow2(int x) { return x > 0 && (x & (x - 1)) == 0; }
 int ilog2(int x) { int l = 0; while ((1 << l) < x) ++l; return l; }

@@ -197,7 +197,7 @@ hipError_t launch_sig_build(selhip_ctx* c, int n_rows, int n_bands, bool with_bo
     hipLaunchKernelGGL(sig_build_kernel, dim3(work_blocks + (unsigned)bounds_blocks), dim3(kBlock), 0, c->stream,
                        c->d_aux, n, c->m, n_rows, n_bands, n_pad, c->sigQ.p, c->sigT.p, c->sigP.p, c->sigG.p,
                        bounds_blocks, c->d_cards, tau, c->mode == SELHIP_MODE_CB_SMH ? 1 : 0, row_map(c, rb, re), c->ecard.p, c->hi.p, c->pcb,
-                       (c->p == 14 && c->group_stage2) ? c->csr_cnt.p : nullptr, (c->p == 14 && c->group_stage2) ? (int)c->csr_cnt.cap : 0, (int)c->cand_begin,
+                       grouping_on(c) ? c->csr_cnt.p : nullptr, grouping_on(c) ? (int)c->csr_cnt.cap : 0, (int)c->cand_begin,
                        with_bounds ? c->seg_cnt.p : nullptr, with_bounds ? (int)c->seg_cnt.cap : 0, c->join_bits == 15 ? 17 : 16,
                        zero_pc, tile_mode ? 1 : 0);
     return hipGetLastError();
@@ -395,7 +395,7 @@ int pipeline_chunks(const selhip_ctx* c) {
     if (!smh || c->pipeline == 0 || c->pipeline == 1 || c->algo == SELHIP_ALGO_HASHJOIN) return 1;   // (the sort join works on all rows at once)
     if (c->pipeline > 1) return std::min(c->pipeline, kMaxChunks);
     const bool sig = c->algo != SELHIP_ALGO_STREAM && c->join_bits <= 16 && sig_supported(c->m, c->n_rows, c->n_bands);
-    if (!sig || !(c->p == 14 && c->group_stage2)) return 1;
+    if (!sig || !grouping_on(c)) return 1;
     const double pairs = (double)pair_bound(c->n, c->row_begin, c->row_end) / std::max(1, c->il_parts);
     return pairs >= kAutoChunkPairs ? 2 : 1;
 }
@@ -428,7 +428,7 @@ size_t csr_stride(int n) { return 5 * (size_t)n + 2; }
 constexpr double kLabelOrderPairs = 4e8;
 constexpr size_t kLabelOrderBytes = (size_t)192 << 20;     // HLL rows beyond this (the Infinity Cache holds 256 MiB): label order
 bool label_order(const selhip_ctx* c) {
-    if (!(c->p == 14 && c->group_stage2)) return false;
+    if (!grouping_on(c)) return false;
     if (c->group_label >= 0) return c->group_label == 1;
     // the bit-plane kernel is bound by its fetches from beyond L2 at every size (cfg3: stage 2a 79 -> 54 us with the label order)
     if (use_bitslices(c)) return true;
@@ -442,7 +442,7 @@ int enqueue_tail(selhip_ctx* c, const Chain& ch, const selhip_int2_t* final_list
                  bool counted, double tau, PassCounters* pc0) {
     const int n = (int)c->n;
     hipStream_t st = ch.io.st;
-    const bool grouped = c->p == 14 && c->group_stage2;
+    const bool grouped = grouping_on(c);
     if (grouped) {
         // bucket the final list by query row so that stage 2a can keep that row in registers across its pairs
         TimerScope t(c, T_GROUP, st);
@@ -585,7 +585,7 @@ int enqueue_pass(selhip_ctx* c) {
         TimerScope t(c, T_PREP);
         hipLaunchKernelGGL(cb_bounds_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream,
                            c->d_cards, n, tau, c->mode == SELHIP_MODE_CB_SMH ? 1 : 0, row_map(c, rb, re), c->ecard.p, c->hi.p, pc0,
-                           (c->p == 14 && c->group_stage2) ? c->csr_cnt.p : nullptr, (c->p == 14 && c->group_stage2) ? (int)c->csr_cnt.cap : 0, (int)c->cand_begin, pc_next,
+                           grouping_on(c) ? c->csr_cnt.p : nullptr, grouping_on(c) ? (int)c->csr_cnt.cap : 0, (int)c->cand_begin, pc_next,
                            c->seg_cnt.p, (int)c->seg_cnt.cap);
         HIPCHK(&c->err, hipGetLastError());
         if (smh_crit && stream_supported(c->m, c->n_rows)) {
@@ -600,7 +600,7 @@ int enqueue_pass(selhip_ctx* c) {
 
     const int chunks = pipeline_chunks(c);
     c->n_chunks_last = chunks;
-    const bool count_in_verify = crit == SELHIP_CRIT_SMH_A && use_sig && !use_hash && c->join_bits <= 16 && c->p == 14 && c->group_stage2;
+    const bool count_in_verify = crit == SELHIP_CRIT_SMH_A && use_sig && !use_hash && c->join_bits <= 16 && grouping_on(c);
     // chunk k's slices of the pass's buffers (one chunk = the whole of each)
     auto chain_of = [&](int k, hipStream_t st, long long b, long long e) {
         const u64 slice = (u64)c->surv.cap / (u64)chunks;
@@ -757,7 +757,7 @@ int ensure_scratch(selhip_ctx* c, size_t surv_cap, size_t res_cap) {
     // matches, several times the final list, so a smaller window only adds empty histogram + estimate launches: 6 -> 2 per chain at cfg5)
     HIPCHK(&c->err, c->counts.ensure(std::min<size_t>(std::max(c->surv.cap, (size_t)c->n), (size_t)1 << 22) * 64));
     HIPCHK(&c->err, c->results.ensure(res_cap));
-    if (c->group_stage2 && c->p == 14) {
+    if (grouping_on(c)) {
         const size_t chunks = (size_t)pipeline_chunks(c);               // every chunk lane has its own row counters and scan scratch
         HIPCHK(&c->err, c->csr_cnt.ensure(chunks * csr_stride((int)c->n)));
         HIPCHK(&c->err, c->csr_start.ensure(chunks * ((size_t)c->n + 2)));

@@ -123,11 +123,15 @@ def read_results(path: str):
 class Selector:
     """One selhip context = one GPU (`selhip_ctx_*`, include/selection_hip.h section 2)."""
 
+    DEFAULT_PARAMS: dict = {}      # selhip_ctx_set_param applied to every new context (the test-suite groups small sets too: "group_min_n" = 0)
+
     def __init__(self, device: int = 0, fp_mode: int = FP_FMA, stream: Optional[int] = None):
         self._lib = hip_lib()
         self._ctx = C.c_void_p()
         check(self._lib.selhip_ctx_create(C.byref(self._ctx), device))
         check(self._lib.selhip_ctx_set_fp_mode(self._ctx, fp_mode), self._ctx)
+        for name, value in self.DEFAULT_PARAMS.items():
+            check(self._lib.selhip_ctx_set_param(self._ctx, name.encode(), int(value)), self._ctx)
         if stream is not None:
             check(self._lib.selhip_ctx_set_stream(self._ctx, C.c_void_p(stream)), self._ctx)
         self.n = 0

@@ -160,6 +160,8 @@ int selhip_ctx_set_candidate_begin(selhip_ctx* ctx, int64_t k_min);
  *                 histogram (hll_union_hist_runs_kernel).  Takes effect at the next upload / attach.
  *   "hist_run"    pairs a wave of stage 2a takes at a time (0 = automatic: 4 on a grouped list; the byte-row kernel: 1, or 4 with the label order);
  *   "hist_blocks" one-wave blocks of the byte-row kernel, "hist_bs_blocks" four-wave blocks of the bit-plane kernel (multiples of 8);
+ *   "group_min_n" sets of up to this many genomes (default 2 048) skip the stage-2 grouping: two latency-bound launches that buy nothing
+ *                 while the whole table stays in cache; 0 = group always
  *   "group_label" stage-2 grouping lays the query-row buckets out by label = a row's smallest partner, so that the pairs of a
  *                 cluster of similar genomes are neighbours in the list and their HLL rows stay in L2 (-1 = automatic: sets
  *                 whose HLL rows exceed 192 MiB and passes of >= 4e8 pairs; 0 off; 1 on);

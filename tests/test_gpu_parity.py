@@ -596,6 +596,67 @@ def test_aux_precision_limit_and_counter_recovery(oracle):
                 assert s["evaluated"] == st["evaluated"] and s["survivors"] == st["survivors"] and s["selected"] == len(want)
 
 
+def test_small_sets_skip_grouping(oracle):
+    """the library's own default: sets of up to 2 048 genomes go to stage 2 ungrouped (no grouping launches); same pairs, same counters,
+    every criterion, with and without chunk lanes; above the limit the list is grouped again"""
+    cfg = SynthConfig("small", 900, 256, 0.9, 0x99, p_aux=8)
+    hll, aux, cards, _, ah = sorted_set(cfg, oracle)
+    r, b = pkg.banding(cfg.m, cfg.tau)
+    with Selector(0) as sel:
+        sel.upload(hll, aux, cards)
+        sel.upload_aux_hll(ah, 8)
+        for min_n in (2048, 0, 899, 900):
+            sel.set_param("group_min_n", min_n)
+            assert sel.get_param("label_order") == (1 if min_n < 900 else 0)
+            for crit in (pkg.CRIT_SMH_A, pkg.CRIT_HLL_A_SMH_A, pkg.CRIT_HLL_A):
+                sel.set_criterion(crit)
+                for lanes in (-1, 2):
+                    sel.set_pipeline(lanes)
+                    want, st = oracle.select(hll, aux, cards, cfg.tau, r, b, use_cb=False, criterion=crit, aux_hll=ah, p_aux=8)
+                    assert_same_pairs(sel.run(cfg.tau, MODE_SMH, r, b), want)
+                    s = sel.stats()
+                    assert s["evaluated"] == st["evaluated"] and s["survivors"] == st["survivors"]
+
+
+def test_signature_cache(oracle):
+    """"sig_cache" = 1 keeps the band signatures across the passes of a context: they must be rebuilt when the band shape, the signature
+    width or the sketches change, and only then -- thresholds, modes, row ranges, interleave parts and criteria in any order vs the oracle"""
+    cfg = make_golden.GOLDEN_SYNTH["synth_flat_n300_m512"]
+    hll, aux, cards, _, _ = sorted_set(cfg, oracle)
+    cfg2 = make_golden.GOLDEN_SYNTH["synth_spread_n600_m64"]
+    hll2, aux2, cards2, _, _ = sorted_set(cfg2, oracle)
+    with Selector(0) as sel:
+        sel.set_param("sig_cache", 1)
+        sel.upload(hll, aux, cards)
+        for tau, shape, bits in ((0.8, None, 16), (0.8, None, 16), (0.5, None, 16), (0.5, (64, 8), 16), (0.5, (64, 8), 15), (0.5, (64, 8), 16), (0.9, None, 16)):
+            r, b = shape or pkg.banding(cfg.m, tau)
+            sel.set_param("join_bits", bits)
+            for mode, use_cb in ((MODE_CB_SMH, True), (MODE_SMH, False)):
+                want, st = oracle.select(hll, aux, cards, tau, r, b, use_cb=use_cb)
+                assert_same_pairs(sel.run(tau, mode, r, b), want)
+                assert sel.stats()["survivors"] == st["survivors"]
+                assert_same_pairs(sel.run(tau, mode, r, b, rows=(40, 211)), want[(want["i"] >= 40) & (want["i"] < 211)])
+        r, b = pkg.banding(cfg.m, 0.8)
+        want, _ = oracle.select(hll, aux, cards, 0.8, r, b)
+        parts = []
+        for part in range(3):
+            sel.set_row_interleave(32, 3, part)
+            parts.append(sel.run(0.8, MODE_CB_SMH, r, b))
+        sel.set_row_interleave(0, 1, 0)
+        cat = np.concatenate(parts)
+        assert_same_pairs(cat[np.lexsort((cat["k"], cat["i"]))], want)
+        # other sketches, same shape of call: the cached signatures of the first set must not survive the upload
+        sel.upload(hll2, aux2, cards2)
+        r2, b2 = pkg.banding(cfg2.m, 0.5)
+        want2, _ = oracle.select(hll2, aux2, cards2, 0.5, r2, b2)
+        for _ in range(2):
+            assert_same_pairs(sel.run(0.5, MODE_CB_SMH, r2, b2), want2)
+        for algo in (ALGO_HASHJOIN, ALGO_STREAM, ALGO_SIG):
+            assert_same_pairs(sel.run(0.5, MODE_CB_SMH, r2, b2, algo=algo), want2)
+        sel.set_param("sig_cache", 0)
+        assert_same_pairs(sel.run(0.5, MODE_CB_SMH, r2, b2), want2)
+
+
 def test_bitplane_histograms(oracle):
     """stage 2a's bit-plane kernel (csrc/kernel_hllbs.cuh) against numpy on register sets whose largest value selects each of its
     instantiations (16 / 24 / 32 / 48 / 64 decoded values), including all-equal rows, an all-zero row and the value 63; and the
