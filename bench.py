@@ -270,7 +270,7 @@ def main():
     sel.set_param("timed_kernel", timed_hist)
     khi = sel.get_param("hll_khi")
     info = {"bitplanes": bool(sel.get_param("hist_bitplanes")), "khi": khi, "planes": 4 if khi <= 16 else (5 if khi <= 32 else 6),
-            "label": bool(sel.get_param("label_order"))}
+            "label": bool(sel.get_param("label_order")), "small": bool(sel.get_param("small_pass_used"))}
     info["layout"] = (f"p=14 registers as 6 bit planes of 512 dwords per genome (12 KiB; {info['planes']} planes non-zero in this set), written once at attach"
                       if info["bitplanes"] else "p=14 registers as bytes (16 KiB per genome)")
     sel.timing(2)
@@ -341,7 +341,8 @@ def main():
                        "criterion": "hll_a+smh_a" if two_stage else "smh_a",
                        "pairs_per_step": pairs_per_step, "selected_pairs": int(totals[2].item()),
                        "stage1_survivors": int(totals[1].item()), "n_ranks_seen": n_ranks_seen,
-                       "hll_layout": info["layout"], "stage2_grouping": "label order" if info["label"] else "query-row order"},
+                       "hll_layout": info["layout"], "stage2_grouping": "label order" if info["label"] else "query-row order",
+                       **({"pass": "one cooperative launch (small_pass_kernel)"} if info["small"] else {})},
             "bucket_pair_comparisons_per_s_nominal": value * cfg.m,
             "kernel_ms": kernels,
         }
@@ -355,6 +356,12 @@ def main():
             in_region = dom_key == "join" and timed_hist == 0
             r1 = join_roofline(pairs_rank0, n_bands, join_q, dom_pass_ms if in_region else detail_ms["join"], launches, dom_span_ms if in_region else -1.0,
                                wkey, "HIP events inside the timed region" if in_region else "HIP events of 5 extra passes after the timed region")
+        elif info["small"]:
+            r1 = {"bound": "latency", "kernel": "small_pass_kernel (the whole pass of a set of <= 2 048 genomes in one cooperative launch: bounds + signatures, "
+                                                "a grid barrier, then join, verification, union histograms and estimator inside each block)",
+                  "avg_launch_ms": stage1_ms / launches if stage1_ms > 0 else None, "launches_per_step": launches, "achieved": None, "peak": None,
+                  "unit": "n/a", "frac": None, "traffic": None,
+                  "note": "a chain of dependent memory round trips on a few waves per CU: no throughput resource is near its limit at this size"}
         elif not used_sig and cfg.m % 128 == 0 and (n_rows & (n_rows - 1)) == 0 and stage1_ms > 0:
             r1 = stream_issue_roofline(cfg.m, n_rows, pairs_rank0 / launches, stage1_ms / launches)
             if r1:

@@ -64,6 +64,7 @@ const char* kTimerNames[T_COUNT] = {"prep", "stage1", "hist", "select", "total",
 
 struct selhip_ctx {
     int device = 0;
+    int dev_cus = 0;                    // compute units of the device (the one-launch pass of a small set needs all 256 of an MI355X)
     hipStream_t stream = nullptr;
     int fp_mode = SELHIP_FP_FMA;
     std::string err;
@@ -120,6 +121,7 @@ struct selhip_ctx {
     // stage 2a on bit planes (kernel_hllbs.cuh): the p = 14 registers of every genome as 6 bit planes, written when the sketches
     // are uploaded / attached (selhip_ctx_upload / _attach; the caller's arrays must not change behind an attached context)
     DevBuf<uint32_t> hll_bs;            // [n][6][512]
+    DevBuf<u64> small_bar;              // the one-launch pass's barrier: 16 group words, 128 bytes apart
     DevBuf<uint8_t> hll_gmax;           // [n] largest register value of each genome
     DevBuf<int> hll_bs_max;             // largest register value of the set (device side)
     int hll_khi = 0;                    // 0 = no planes; else max register value + 1
@@ -143,6 +145,8 @@ struct selhip_ctx {
                                         // the 1 024 SIMDs better), cfg4 2.12 / 2.10 / 2.07 ms (a block's prologue -- 32 candidate loads per lane,
                                         // tile staging -- is amortised over more rows), cfg5 8.31 / 8.16 / 8.20 ms
     bool group_stage2 = true;           // bucket survivors by query row before stage 2a (hll_union_hist_runs_kernel)
+    int small_pass = -1;                // sets of <= 2 048 genomes: the whole pass in one cooperative launch (kernel_small.cuh); -1 automatic, 0 off
+    bool small_used = false, small_pass_failed = false;   // the last enqueue took it / a block's survivor list overflowed once: regular passes from then on
     int group_min_n = 2048;             // ... for sets of more than this many genomes ("group_min_n"; see grouping_on)
 
     // last run parameters (for overflow re-runs)

@@ -539,6 +539,61 @@ int enqueue_chain(selhip_ctx* c, const Chain& ch, int rb, int re, double tau, bo
     return enqueue_tail(c, ch, final_list, final_count, final_cap, count_in_verify, tau, pc0);
 }
 
+// ---- the whole pass of a small set in one cooperative launch (kernel_small.cuh) ------------------------------------------------
+bool small_pass_ok(const selhip_ctx* c) {
+    if (c->small_pass == 0 || c->small_pass_failed) return false;
+    if (c->n < 2 || c->n > kSmallPassMaxN || c->criterion != SELHIP_CRIT_SMH_A || c->il_parts > 1) return false;
+    if (!(c->algo == SELHIP_ALGO_AUTO || c->algo == SELHIP_ALGO_SIG) || !sig_supported(c->m, c->n_rows, c->n_bands)) return false;
+    if (!(is_pow2(c->m) && c->n_rows >= 2 && c->n_rows <= 32 && c->m >= 4)) return false;          // the tiled signature build
+    if ((c->row_end - c->row_begin + 255) / 256 > kSmallRows) return false;                        // rows per block of the 256-block grid
+    if (c->dev_cus < 256) return false;                                                            // (a partitioned or masked device: the regular pass)
+    return use_bitslices(c) && c->hll_khi <= 32;                                                   // bit planes, at most five of them non-zero
+}
+
+hipError_t hipModuleLaunchKernel_like(selhip_ctx* c, const void* fn, unsigned grid, void** args) {
+    return hipLaunchKernel(fn, dim3(grid), dim3(kBlock), args, 0, c->stream);
+}
+
+template <bool FMA, int NB>
+hipError_t launch_small_pass(selhip_ctx* c, PassCounters* pc_next, double tau) {
+    int n = (int)c->n;
+    int n_pad = ((n + kWave - 1) / kWave) * kWave;
+    RowMap rm = row_map(c, (int)c->row_begin, (int)c->row_end);
+    int m = c->m, r = c->n_rows, nb = c->n_bands, use_cb = c->mode == SELHIP_MODE_CB_SMH ? 1 : 0, cand_begin = (int)c->cand_begin, fb = c->verify_fb;
+    const u64* aux = c->d_aux; const double* cards = c->d_cards; const uint32_t* bs = c->hll_bs.p; const uint8_t* gmax = c->hll_gmax.p;
+    uint32_t *sQ = c->sigQ.p, *sT = c->sigT.p, *sP = c->sigP.p, *sG = c->sigG.p;
+    u64* ecard = c->ecard.p; int* hi = c->hi.p; PassCounters* pc = c->pcb;
+    u64* barrier_word = &c->pcb[kMaxChunks].n_aux_in;                   // a word of this pass's counter set that nothing else uses (cleared by the previous pass)
+    if (!c->small_bar.p) {                                               // the barrier's group words: zero between passes (the kernel puts them back)
+        hipError_t e = c->small_bar.ensure((size_t)kSmallBarGroups * kSmallBarStride);
+        if (e == hipSuccess) e = hipMemsetAsync(c->small_bar.p, 0, sizeof(u64) * kSmallBarGroups * kSmallBarStride, c->stream);
+        if (e != hipSuccess) return e;
+    }
+    u64* barrier_groups = c->small_bar.p;
+    double rs = relerr_scaled_for(14);
+    selhip_pair_t* results = c->results.p; u64 results_cap = (u64)c->results.cap;
+    void* args[] = {&aux, &cards, &bs, &gmax, &n, &m, &r, &nb, &n_pad, &tau, &use_cb, &rm, &cand_begin, &sQ, &sT, &sP, &sG, &ecard, &hi, &pc, &pc_next,
+                    &barrier_word, &barrier_groups, &rs, &results, &results_cap, &fb};
+    const unsigned grid = 256;                                           // one block per CU (small_pass_ok checked that the device has 256)
+    // an ordinary launch: 256 blocks of 256 threads with 60 KB of LDS and <= 250 registers -- a CU holds two, the device 512 -- all become
+    // resident as soon as whatever else is running drains, which is all the kernel's one barrier needs (work of the same stream is over
+    // by then; nothing another stream runs waits for this kernel); hipLaunchCooperativeKernel ("small_pass" = 2) asks the runtime for
+    // that guarantee and costs ~15 us more per launch
+    if (c->small_pass == 2) return hipLaunchCooperativeKernel((const void*)small_pass_kernel<FMA, NB>, dim3(grid), dim3(kBlock), args, 0, c->stream);
+    return hipModuleLaunchKernel_like(c, (const void*)small_pass_kernel<FMA, NB>, grid, args);
+}
+
+int enqueue_small_pass(selhip_ctx* c, PassCounters* pc_next, double tau) {
+    TimerScope t(c, T_STAGE1);
+    const bool fma = c->fp_mode == SELHIP_FP_FMA;
+    c->sig_key = 0;                                                      // (the kernel rewrites the 32-bit signature layouts only)
+    hipError_t e;
+    if (c->hll_khi <= 16) e = fma ? launch_small_pass<true, 4>(c, pc_next, tau) : launch_small_pass<false, 4>(c, pc_next, tau);
+    else                  e = fma ? launch_small_pass<true, 5>(c, pc_next, tau) : launch_small_pass<false, 5>(c, pc_next, tau);
+    HIPCHK(&c->err, e);
+    return SELHIP_OK;
+}
+
 int enqueue_pass(selhip_ctx* c) {
     const int n = (int)c->n;
     const int rb = (int)c->row_begin, re = (int)c->row_end;
@@ -578,6 +633,15 @@ int enqueue_pass(selhip_ctx* c) {
     c->pc_dirty = true;                                  // until this function returns SELHIP_OK
     PassCounters* pc0 = c->pcb;
     if (c->fail_after_flip) { c->fail_after_flip = 0; set_err(&c->err, "test hook: enqueue failed after the counter flip"); return SELHIP_E_HIP; }
+    c->small_used = small_pass_ok(c);
+    if (c->small_used) {
+        c->n_chunks_last = 1;
+        const int rc = enqueue_small_pass(c, pc_next, tau);
+        if (rc) return rc;
+        HIPCHK(&c->err, hipMemcpyAsync(c->h_pc, c->pcb, sizeof(PassCounters) * (kMaxChunks + 1), hipMemcpyDeviceToHost, c->stream));
+        c->pc_dirty = false;
+        return SELHIP_OK;
+    }
     if (use_sig) {
         // bounds (truncated cards, CB cut-offs, z0, evaluated count) ride in the first blocks of the signature build
         HIPCHK(&c->err, launch_sig_build(c, c->n_rows, c->n_bands, true, tau, rb, re, pc_next));

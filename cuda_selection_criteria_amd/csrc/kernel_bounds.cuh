@@ -20,10 +20,11 @@ __device__ __forceinline__ bool cb_pred(double tau, u64 e1, u64 e2) {
     return gamma >= tau;
 }
 
-__device__ __forceinline__ void cb_bounds_body(int i, const double* __restrict__ cards, int n, double tau, int use_cb,
-                                               RowMap rm, u64* __restrict__ ecard, int* __restrict__ hi,
-                                               PassCounters* __restrict__ pc, int cand_begin) {
-    if (i >= n) return;
+// returns the row's pairs inside the pair space when `count_only` (the caller adds them up); otherwise adds them to pc->n_evaluated itself
+__device__ __forceinline__ long long cb_bounds_body(int i, const double* __restrict__ cards, int n, double tau, int use_cb,
+                                                    RowMap rm, u64* __restrict__ ecard, int* __restrict__ hi,
+                                                    PassCounters* __restrict__ pc, int cand_begin, bool count_only = false) {
+    if (i >= n) return 0;
     double c = cards[i];
     u64 e1 = selhip::trunc_card(c);
     ecard[i] = e1;
@@ -62,8 +63,12 @@ __device__ __forceinline__ void cb_bounds_body(int i, const double* __restrict__
         }
         if (first < cand_begin) first = cand_begin;
         long long cnt = (long long)h - first + 1;
-        if (cnt > 0) atomicAdd(&pc->n_evaluated, (u64)cnt);
+        if (cnt > 0) {
+            if (count_only) return cnt;
+            atomicAdd(&pc->n_evaluated, (u64)cnt);
+        }
     }
+    return 0;
 }
 
 // the counter blocks of the NEXT pass (the other of the context's two sets) are cleared by the first kernel of this one

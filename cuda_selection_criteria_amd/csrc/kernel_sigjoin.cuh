@@ -101,10 +101,13 @@ constexpr int kSigTileG = 16;
 
 __device__ __forceinline__ void sig_build_tile_body(int tile, const u64* __restrict__ aux, int n, int m, int r, int nb, int n_pad,
                                                     uint32_t* __restrict__ sigQ, uint32_t* __restrict__ sigT, uint32_t* __restrict__ sigP,
-                                                    uint32_t* __restrict__ sigG, int pk_shift) {
+                                                    uint32_t* __restrict__ sigG, int pk_shift,
+                                                    int tg = kSigTileG, bool all_layouts = true) {
+    // (tg <= kSigTileG genomes per tile: the one-launch pass of a small set spreads ITS genomes over all its blocks; it only reads the
+    //  32-bit layouts sigQ / sigT and leaves the packed ones alone)
     __shared__ uint32_t sig_lds[kSigTileG][129];                          // pitch 129: the band-major read-out is conflict-free
-    const int g0 = tile * kSigTileG;
-    const int ng = min(kSigTileG, n - g0);
+    const int g0 = tile * tg;
+    const int ng = min(tg, n - g0);
     if (ng <= 0) return;
     const int lr = __builtin_ctz((unsigned)r), lm = __builtin_ctz((unsigned)m);
     const int half_m = m >> 1;                                            // bucket pairs per genome
@@ -140,14 +143,15 @@ __device__ __forceinline__ void sig_build_tile_body(int tile, const u64* __restr
         const int gl = idx / nb, b = idx - gl * nb;
         const uint32_t sig = sig_lds[gl][b];
         sigQ[(size_t)(g0 + gl) * nb + b] = sig;
-        sigG16[(size_t)(g0 + gl) * (2 * ndw) + b] = (uint16_t)(sig >> pk_shift);
+        if (all_layouts) sigG16[(size_t)(g0 + gl) * (2 * ndw) + b] = (uint16_t)(sig >> pk_shift);
     }
-    for (int idx = threadIdx.x; idx < nb * kSigTileG; idx += kBlock) {     // band-major: kSigTileG consecutive genomes per band
-        const int b = idx / kSigTileG, gl = idx - b * kSigTileG;
+    for (int idx = threadIdx.x; idx < nb * tg; idx += kBlock) {            // band-major: tg consecutive genomes per band
+        const int b = idx / tg, gl = idx - b * tg;
         if (gl < ng) sigT[(size_t)b * n_pad + g0 + gl] = sig_lds[gl][b];
     }
-    for (int idx = threadIdx.x; idx < ndw * kSigTileG; idx += kBlock) {
-        const int d = idx / kSigTileG, gl = idx - d * kSigTileG;
+    if (!all_layouts) return;
+    for (int idx = threadIdx.x; idx < ndw * tg; idx += kBlock) {
+        const int d = idx / tg, gl = idx - d * tg;
         if (gl < ng) {
             const uint32_t lo = sig_lds[gl][2 * d] >> pk_shift, hi2 = (2 * d + 1 < nb) ? (sig_lds[gl][2 * d + 1] >> pk_shift) : 0u;
             sigP[(size_t)d * n_pad + g0 + gl] = (lo & 0xFFFFu) | (hi2 << 16);

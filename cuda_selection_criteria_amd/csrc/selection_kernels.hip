@@ -17,6 +17,7 @@
 //   kernel_hllbs.cuh    hll_bitslice_kernel, hll_union_hist_bs_kernel: stage 2a on bit-sliced registers (bit-serial max, decode tree, v_bcnt)
 //   kernel_pairlist.cuh explicit pair lists (drop-in launch_kernel_* path, test building blocks)
 //   kernel_sketch.cuh   synth_kernel, sketch_build_kernel (build_sketch on the GPU), permute_rows
+//   kernel_small.cuh    small_pass_kernel: the whole pass of a set of <= 2 048 genomes in one cooperative launch
 //
 // Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off (see csrc/Makefile).
 #include <hip/hip_runtime.h>
@@ -49,6 +50,7 @@
 #include "kernel_hllbs.cuh"
 #include "kernel_pairlist.cuh"
 #include "kernel_sketch.cuh"
+#include "kernel_small.cuh"
 
 #include "host_context.hpp"      // struct selhip_ctx, device buffers, timers, helpers
 #include "host_pass.hpp"         // pass scheduler: dispatch of every stage, chunk lanes, scratch sizing

@@ -160,6 +160,9 @@ int selhip_ctx_set_candidate_begin(selhip_ctx* ctx, int64_t k_min);
  *                 histogram (hll_union_hist_runs_kernel).  Takes effect at the next upload / attach.
  *   "hist_run"    pairs a wave of stage 2a takes at a time (0 = automatic: 4 on a grouped list; the byte-row kernel: 1, or 4 with the label order);
  *   "hist_blocks" one-wave blocks of the byte-row kernel, "hist_bs_blocks" four-wave blocks of the bit-plane kernel (multiples of 8);
+ *   "small_pass"  -1 (default) / 1: a set of up to 2 048 genomes with criterion smh_a takes its whole pass in ONE cooperative launch
+ *                 (small_pass_kernel: bounds + signatures, a grid barrier, then join, verification, union histograms and estimator
+ *                 inside each block); 0: the regular chain of launches
  *   "group_min_n" sets of up to this many genomes (default 2 048) skip the stage-2 grouping: two latency-bound launches that buy nothing
  *                 while the whole table stays in cache; 0 = group always
  *   "group_label" stage-2 grouping lays the query-row buckets out by label = a row's smallest partner, so that the pairs of a
@@ -170,7 +173,7 @@ int selhip_ctx_set_candidate_begin(selhip_ctx* ctx, int64_t k_min);
  * knobs, listed at selhip_ctx_set_param in csrc/selection_kernels.hip.) */
 int selhip_ctx_set_param(selhip_ctx* ctx, const char* name, int value);
 /* what the context decided (read-only): "hll_khi" (largest p = 14 register value + 1; 0 = no bit planes), "hist_bitplanes",
- * "label_order", "join_tile_rows", "chunks" (chunk lanes of the last pass) */
+ * "label_order", "join_tile_rows", "chunks" (chunk lanes of the last pass), "small_pass_used" (the last pass was the one-launch small pass) */
 int selhip_ctx_get_param(const selhip_ctx* ctx, const char* name, int* value);
 /* Stage 2 grouping (default on): the pairs that reach the HLL-14 stage are bucketed by query row (counting sort) so
  * that waves running side by side on one XCD share their query row in L2.  0 = off (same kernel, list as produced). */

@@ -28,10 +28,12 @@ def _ensure_built():
 
 _ensure_built()
 
-# the library skips the stage-2 grouping for sets of up to 2 048 genomes (BASELINE configs[1]); nearly every parity case is that small,
-# so the suite switches the grouping on at every size and tests the small-set default on its own (test_small_sets_skip_grouping)
+# For sets of up to 2 048 genomes (BASELINE configs[1]) the library skips the stage-2 grouping and, for criterion smh_a, runs the whole pass
+# in one launch (small_pass_kernel).  Nearly every parity case is that small, so the suite switches both off -- its cases then run the
+# kernels the BASELINE-sized sets run -- and tests the small-set defaults on their own (test_small_sets_skip_grouping,
+# test_small_pass_one_launch)
 import cuda_selection_criteria_amd as _pkg  # noqa: E402
-_pkg.Selector.DEFAULT_PARAMS = {"group_min_n": 0}
+_pkg.Selector.DEFAULT_PARAMS = {"group_min_n": 0, "small_pass": 0}
 
 
 @pytest.fixture(scope="session")

@@ -618,6 +618,84 @@ def test_small_sets_skip_grouping(oracle):
                     assert s["evaluated"] == st["evaluated"] and s["survivors"] == st["survivors"]
 
 
+def test_small_pass_one_launch(oracle):
+    """sets of up to 2 048 genomes with criterion smh_a take their whole pass in ONE cooperative launch (small_pass_kernel): same pairs,
+    Jaccard bits and counters as the oracle -- and as the regular chain -- for both modes, row ranges, candidate ranges, both FP
+    flavours, empty sketches, band shapes with long bands; an overflowing block list falls back to the regular pass"""
+    for name, tau in (("synth_flat_n1000_m256", 0.9), ("synth_spread_n600_m64", 0.5), ("synth_flat_n300_m512", 0.5), ("synth_flat_n200_m128", 0.9)):
+        cfg = make_golden.GOLDEN_SYNTH[name]
+        for fp_mode in (FP_FMA, FP_STRICT):
+            hll, aux, cards, _, _ = sorted_set(cfg, oracle, fp_mode)
+            oracle.set_fma(fp_mode)
+            try:
+                r, b = pkg.banding(cfg.m, tau)
+                with Selector(0, fp_mode) as sel:
+                    sel.set_param("sig_cache", 1 if fp_mode == FP_STRICT else 0)     # (the one-launch pass rewrites part of the cached signatures)
+                    sel.upload(hll, aux, cards)
+                    for mode, use_cb in ((MODE_CB_SMH, True), (MODE_SMH, False)):
+                        want, st = oracle.select(hll, aux, cards, tau, r, b, use_cb=use_cb)
+                        for small in (1, 0, -1):
+                            sel.set_param("small_pass", small)
+                            got = sel.run(tau, mode, r, b)
+                            assert sel.get_param("small_pass_used") == (1 if small else 0)
+                            assert_same_pairs(got, want)
+                            s = sel.stats()
+                            assert s["evaluated"] == st["evaluated"] and s["survivors"] == st["survivors"] and s["selected"] == len(want), (name, small, s, st)
+                        lo, hi_ = 37, min(211, hll.shape[0])
+                        assert_same_pairs(sel.run(tau, mode, r, b, rows=(lo, hi_)), want[(want["i"] >= lo) & (want["i"] < hi_)])
+                        assert sel.get_param("small_pass_used") == 1
+                    sel.set_candidate_begin(100)
+                    want_r, _ = oracle.select(hll, aux, cards, tau, r, b)
+                    got = sel.run(tau, MODE_CB_SMH, r, b, rows=(0, 100))
+                    assert_same_pairs(got, want_r[(want_r["i"] < 100) & (want_r["k"] >= 100)])
+                    sel.set_candidate_begin(0)
+            finally:
+                oracle.set_fma(1)
+    # genomes with zero cardinality and duplicates; many passes in a row (the barrier word lives in the double-buffered counter sets)
+    cfg = SynthConfig("small-edge", 130, 128, 0.9, 77, n_sh_lo=5000, n_sh_hi=5000)
+    hll, aux, cards, _, _ = sorted_set(cfg, oracle)
+    hll[:5] = 0; hll[7] = hll[6]; aux[7] = aux[6]
+    cards = oracle.cards(hll)
+    perm = pkg.sort_by_card(cards)
+    hll, aux, cards = hll[perm], aux[perm], cards[perm]
+    with Selector(0) as sel:
+        sel.set_param("small_pass", -1)
+        sel.upload(hll, aux, cards)
+        for rows in (2, 4, 8, 16):
+            want, st = oracle.select(hll, aux, cards, 0.3, rows, 128 // rows, use_cb=False)
+            for _ in range(3):
+                assert_same_pairs(sel.run(0.3, MODE_SMH, rows, 128 // rows), want)
+                assert sel.get_param("small_pass_used") == 1 and sel.stats()["survivors"] == st["survivors"]
+        for rows in (1, 32, 64):                               # shapes the one-launch pass does not take (one row per band; fewer than 8 bands)
+            want, _ = oracle.select(hll, aux, cards, 0.3, rows, 128 // rows, use_cb=False)
+            assert_same_pairs(sel.run(0.3, MODE_SMH, rows, 128 // rows), want)
+            assert sel.get_param("small_pass_used") == 0
+    # the largest sets the pass takes: eight rows per block, two rounds of 1 024 candidates, partial last chunk; with and without CB
+    cfg = SynthConfig("small-max", 2041, 64, 0.8, 78, mode=1, n_sh_lo=5000, n_sh_hi=40000)
+    hll2, aux2, cards2, _, _ = sorted_set(cfg, oracle)
+    r, b = pkg.banding(cfg.m, 0.8)
+    with Selector(0) as sel:
+        sel.set_param("small_pass", -1)
+        sel.upload(hll2, aux2, cards2)
+        for mode, use_cb in ((MODE_CB_SMH, True), (MODE_SMH, False)):
+            want, st = oracle.select(hll2, aux2, cards2, 0.8, r, b, use_cb=use_cb)
+            assert_same_pairs(sel.run(0.8, mode, r, b), want)
+            s = sel.stats()
+            assert sel.get_param("small_pass_used") == 1 and s["evaluated"] == st["evaluated"] and s["survivors"] == st["survivors"]
+            assert_same_pairs(sel.run(0.8, mode, r, b, rows=(1000, 2041)), want[want["i"] >= 1000])
+    # every sketch equal: each row keeps all its candidates, a block's LDS list (2 048 pairs) overflows -> regular pass, same result
+    n = 1800
+    hll1 = np.tile(hll[10], (n, 1)); aux1 = np.tile(aux[10], (n, 1)); cards1 = np.full(n, cards[10])
+    with Selector(0) as sel:
+        sel.set_param("small_pass", -1)
+        sel.upload(hll1, aux1, cards1)
+        got = sel.run(0.9, MODE_SMH, 16, 8)
+        assert len(got) == n * (n - 1) // 2 and sel.get_param("small_pass_used") == 0 and sel.last_attempts() >= 2
+        assert (got["jaccard"] == got["jaccard"][0]).all()
+        got = sel.run(0.9, MODE_SMH, 16, 8)                    # ... and the context remembers
+        assert len(got) == n * (n - 1) // 2 and sel.last_attempts() == 1
+
+
 def test_signature_cache(oracle):
     """"sig_cache" = 1 keeps the band signatures across the passes of a context: they must be rebuilt when the band shape, the signature
     width or the sketches change, and only then -- thresholds, modes, row ranges, interleave parts and criteria in any order vs the oracle"""
