@@ -76,7 +76,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip stream_kernel / harder_workload (profiling runs)")
     ap.add_argument("--no-grouping", action="store_true", help="stage 2 without bucketing the survivors by query row")
-    ap.add_argument("--pipeline", type=int, default=-1, help="-1 auto (2 chunk lanes from 1e9 pairs per pass), 0 off, 2..8 row chunks, each a whole chain on one of two streams")
+    ap.add_argument("--pipeline", type=int, default=-1, help="-1 auto (2 chunk lanes from 5e8 pairs per pass), 0 off, 2..8 row chunks, each a whole chain on one of two streams")
     ap.add_argument("--pcie", action="store_true", help="also time a PCIe-inclusive pass (host buffers -> upload -> run)")
     ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed and run the collectives even with one rank (RCCL smoke test)")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
@@ -599,7 +599,7 @@ def join_roofline(pairs, n_bands, join_q, pass_ms, launches, span_ms, wkey, cloc
                          f"frac_vs_measured_mix_rate: {CYC_MIX_MEASURED} cycles, the measured rate of the alternating xor / packed-min mix (3.76-3.95)"}
     if launches > 1.5 and span_ms > 0:
         r["concurrent_launches"] = {"span_ms": span_ms, "frac_of_chip_while_running": row_waves * n_instr / (span_ms * 1e-3) / peak,
-                                    "note": "this pass is cut into row chunks whose chains run on two streams (selhip_ctx_set_pipeline, automatic from 1e9 pairs): the join "
+                                    "note": "this pass is cut into row chunks whose chains run on two streams (selhip_ctx_set_pipeline, automatic from 5e8 pairs): the join "
                                             "launches run side by side, each on about half of the chip, so `frac` (work of a launch / its own duration / whole-chip peak) is "
                                             "about half of what the chip delivers while they run; span_ms = first start to last end of the pass's join launches.  --pipeline 0 "
                                             "gives the single-launch figure"}

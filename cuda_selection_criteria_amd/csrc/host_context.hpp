@@ -52,7 +52,10 @@ struct KernelTimer {
 
 constexpr int kMaxChunks = 8;
 constexpr size_t kSegCounterSlots = (size_t)(kMaxChunks + 1) * kAppendSegs * kSegStride;    // the join's append-segment counters (u64 slots)
-constexpr double kAutoChunkPairs = 1e9;  // pairs per pass from which the automatic setting splits a pass into two chunk lanes
+// pairs per pass from which the automatic setting splits a pass into two chunk lanes (one MI355X, cfg3 data at growing genome counts,
+// lanes off -> 2: 4.0e8 pairs 1.033 -> 1.034 ms, 5.4e8 1.319 -> 1.289, 7.2e8 1.648 -> 1.622, 1.0e9 2.290 -> 2.154; an eighth of cfg4's rows,
+// 6.2e8 pairs, 0.446 -> 0.431 ms)
+constexpr double kAutoChunkPairs = 5e8;
 static_assert(kCounterBlocks == kMaxChunks + 1, "common.cuh: counter blocks per pass");
 constexpr int kMaxAuxP = SELHIP_MAX_AUX_P;   // auxiliary HLL precision accepted by every entry point: aux_fused_kernel counts in 16-bit bins (a bin holds up to 2^p_aux)
 constexpr long long kEnumPairs = 1ll << 26;    // hll_a / hll_an as first criterion: pairs listed per sub-pass (512 MiB of int2)
@@ -126,6 +129,7 @@ struct selhip_ctx {
     DevBuf<int> hll_bs_max;             // largest register value of the set (device side)
     int hll_khi = 0;                    // 0 = no planes; else max register value + 1
     int hist_algo = -1;                 // -1 automatic (bit planes when p = 14), 0 = byte rows + LDS histogram (hll_union_hist_runs_kernel), 1 = bit planes
+    int hist_dense_degree = 32;         // bit-plane kernel: survivors per genome from which a grouped list is walked by candidate slice per XCD (-1 = never)
     int hist_bs_blocks = 2048;          // bit-plane kernel: 4-wave blocks (multiple of 8)
     int group_label = -1;               // grouping: lay the query-row buckets out by label (kernel_hll.cuh): -1 = automatic (HLL rows beyond kLabelOrderBytes), 0 off, 1 on
     int verify_fb = 0;                  // test hook: force the collision fallback of verify16_kernel

@@ -292,8 +292,8 @@ unsigned grid_for(u64 items, unsigned per_block, unsigned max_blocks) {
 // ---- stage 2a on bit planes (kernel_hllbs.cuh) -------------------------------------------------
 // the instantiation for a set whose largest register value is khi - 1 = the number of bit planes that can be non-zero
 hipError_t launch_hist_bs(int khi, unsigned blocks, hipStream_t st, const uint32_t* bs, const uint8_t* gmax, const selhip_int2_t* list, const u64* count,
-                          u64 cap, uint32_t* counts, u64 off, u64 window, int run) {
-#define SELHIP_BS_LAUNCH(NB) hipLaunchKernelGGL((hll_union_hist_bs_kernel<NB>), dim3(blocks), dim3(kBlock), 0, st, bs, gmax, list, count, cap, counts, off, window, run)
+                          u64 cap, uint32_t* counts, u64 off, u64 window, int run, u64 dense_pairs) {
+#define SELHIP_BS_LAUNCH(NB) hipLaunchKernelGGL((hll_union_hist_bs_kernel<NB>), dim3(blocks), dim3(kBlock), 0, st, bs, gmax, list, count, cap, counts, off, window, run, dense_pairs)
     if (khi <= 16)      SELHIP_BS_LAUNCH(4);
     else if (khi <= 32) SELHIP_BS_LAUNCH(5);
     else                SELHIP_BS_LAUNCH(6);
@@ -492,7 +492,9 @@ int enqueue_tail(selhip_ctx* c, const Chain& ch, const selhip_int2_t* final_list
             TimerScope t(c, T_HIST, st);
             if (use_bitslices(c))
                 HIPCHK(&c->err, launch_hist_bs(c->hll_khi, (unsigned)c->hist_bs_blocks, st, c->hll_bs.p, c->hll_gmax.p, final_list, final_count, final_cap, ch.counts, off, ch.window,
-                                               c->hist_run > 0 ? c->hist_run : (grouped ? 4 : 1)));
+                                               c->hist_run > 0 ? c->hist_run : (grouped ? 4 : 1),
+                                               // a dense survivor graph is walked by candidate-row slice per XCD (query-major list only)
+                                               grouped && c->hist_dense_degree >= 0 ? (u64)c->hist_dense_degree * (u64)c->n : ~0ull));
             else if (c->p == 14)
                 hipLaunchKernelGGL(hll_union_hist_runs_kernel, dim3(c->hist_blocks), dim3(kWave), (size_t)c->hist_pad, st,
                                    c->d_hll, final_list, final_count, final_cap, ch.counts, off, ch.window,

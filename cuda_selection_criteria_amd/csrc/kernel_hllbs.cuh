@@ -224,7 +224,7 @@ __device__ __forceinline__ uint32_t bs_pair_hist(const uint32_t (&xa)[NB][8], co
 }
 
 // hll_union_hist_bs_kernel<NB>: same contract as hll_union_hist_runs_kernel (window [chunk_off, chunk_off + chunk_len) of the
-// pair list, counts indexed from the window start, tasks of run_len consecutive pairs, block b works in the (b % 8)-th eighth of
+// pair list, counts indexed from the window start, tasks of run_len (at most 64) consecutive pairs, block b works in the (b % 8)-th eighth of
 // the tasks = on XCD b % 8), on the bit planes.  NB = planes that can be non-zero in the SET (4, 5 or 6); how many values are
 // decoded is decided PER PAIR from the two rows' largest register values (gmax, written with the planes).
 // One wave per pair: a lane owns 8 dwords (256 registers) of every plane; the query row's planes stay in registers across a run.
@@ -232,7 +232,7 @@ template <int NB>
 __global__ __launch_bounds__(kBlock, NB <= 5 ? 4 : 2)
 void hll_union_hist_bs_kernel(const uint32_t* __restrict__ bs, const uint8_t* __restrict__ gmax, const selhip_int2_t* __restrict__ pairs,
                               const u64* __restrict__ n_pairs_dev, u64 cap, uint32_t* __restrict__ counts,
-                              u64 chunk_off, u64 chunk_len, int run_len) {
+                              u64 chunk_off, u64 chunk_len, int run_len, u64 dense_pairs) {
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = threadIdx.x / kWave;
     u64 n_pairs = *n_pairs_dev;
@@ -240,27 +240,39 @@ void hll_union_hist_bs_kernel(const uint32_t* __restrict__ bs, const uint8_t* __
     n_pairs = n_pairs > chunk_off ? min(n_pairs - chunk_off, chunk_len) : 0;
     pairs += chunk_off;
     const u64 stride = (u64)(gridDim.x >> 3) * kWavesPerBlock;            // waves per XCD (the host launches a multiple of 8 blocks)
+    const int my_bin = ((lane & 2) ? 32 : 0) + 2 * bs_pidx(lane) + (lane & 1);
+    // A DENSE survivor graph (n_pairs >= dense_pairs; the host sets 32 pairs per genome on a grouped list, "hist_dense_degree"): a query
+    // row has tens to hundreds of partners spread over the whole table, the table does not fit one L2 (4 MiB = ~400 rows) and in list
+    // order every pair fetches its candidate row from beyond it (the 25 %-degenerate set of bench.py: 730 000 pairs among 2 516 genomes,
+    // 6.2 GB per pass at 92 % of the Infinity Cache's gather rate).  Then every XCD walks the WHOLE list, 64 pairs per task, and takes
+    // the pairs whose candidate row hashes to it: its L2 only ever sees an eighth of the candidate rows (they stay) plus the query rows,
+    // which all its waves pass through together (the list is query-major).  Same counts in the same slots either way.
+    const bool dense = n_pairs >= dense_pairs;
+    const uint32_t xcd = blockIdx.x & 7u;
     // a short list is dealt out pair by pair: runs only pay (the query row stays in registers) once every wave has several of them --
     // one of 8 ranks of cfg4, 28 000 pairs on 8 192 waves: 49.9 us with single pairs, 58.3 us with runs of 4
-    run_len = (int)max((u64)1, min((u64)run_len, n_pairs / (16 * stride)));
+    run_len = dense ? kWave : (int)max((u64)1, min((u64)min(run_len, kWave), n_pairs / (16 * stride)));
     const u64 n_tasks = (n_pairs + run_len - 1) / run_len;
-    const u64 tasks_per_xcd = (n_tasks + 7) >> 3;
-    const u64 t_begin = (u64)(blockIdx.x & 7) * tasks_per_xcd, t_end = min(t_begin + tasks_per_xcd, n_tasks);
-    const int my_bin = ((lane & 2) ? 32 : 0) + 2 * bs_pidx(lane) + (lane & 1);
+    const u64 tasks_per_xcd = dense ? n_tasks : (n_tasks + 7) >> 3;
+    const u64 t_begin = dense ? 0 : (u64)xcd * tasks_per_xcd, t_end = min(t_begin + tasks_per_xcd, n_tasks);
     int cur_x = -1;
     uint32_t xa[NB][8];
     for (u64 task = t_begin + (u64)(blockIdx.x >> 3) * kWavesPerBlock + wave; task < t_end; task += stride) {
-        const u64 j0 = task * run_len, j1 = min(j0 + run_len, n_pairs);
-        selhip_int2_t pr = pairs[j0];
-        for (u64 j = j0; j < j1; ++j) {
-            const int px = __builtin_amdgcn_readfirstlane(pr.x), py = __builtin_amdgcn_readfirstlane(pr.y);   // wave-uniform: scalar row addresses
+        const u64 j0 = task * run_len;
+        const int cnt = (int)min((u64)run_len, n_pairs - j0);
+        selhip_int2_t pr{0, 0};
+        if (lane < cnt) pr = pairs[j0 + lane];                            // the task's pairs, one per lane
+        u64 mine = __ballot(lane < cnt && (!dense || (((uint32_t)pr.y * 0x9E3779B1u) >> 29) == xcd));
+        while (mine) {
+            const int src = (int)__builtin_ctzll(mine);
+            mine &= mine - 1;
+            const int px = __builtin_amdgcn_readlane(pr.x, src), py = __builtin_amdgcn_readlane(pr.y, src);   // wave-uniform: scalar row addresses
             uint32_t yb[NB][8];
             bs_load<NB>(bs, py, lane, yb);
             if (px != cur_x) { bs_load<NB>(bs, px, lane, xa); cur_x = px; }
             const int kp = max((int)gmax[px], (int)gmax[py]) + 1;         // values this pair can hold: [0, kp)
-            if (j + 1 < j1) pr = pairs[j + 1];
             const uint32_t tot = bs_pair_hist<NB>(xa, yb, kp, lane);
-            counts[j * 64 + my_bin] = (lane & 1) ? (tot >> 16) : (tot & 0xFFFFu);
+            counts[(j0 + src) * 64 + my_bin] = (lane & 1) ? (tot >> 16) : (tot & 0xFFFFu);
         }
     }
 }

@@ -125,7 +125,7 @@ int selhip_ctx_set_stream(selhip_ctx* ctx, void* hip_stream);
 /* Chunk lanes of a pass (smh_a / hll_a+smh_a): the query rows are cut into `chunks` equal-pair chunks and every chunk runs its
  * whole chain (join, verify, [auxiliary criterion], grouping, HLL union histograms, estimate) on one of two internal streams
  * (the context's own and one more), so that one chunk's short tail kernels run beside the other chunk's join.
- * -1 = automatic (the default: 2 chunks from 1e9 pairs per pass with the signature join, else 1), 0 / 1 = off, 2..8 = chunk
+ * -1 = automatic (the default: 2 chunks from 5e8 pairs per pass with the signature join, else 1), 0 / 1 = off, 2..8 = chunk
  * count.  Results and counters do not depend on it.  (Round 1's stage-1-stream / stage-2-stream pipeline was replaced.) */
 int selhip_ctx_set_pipeline(selhip_ctx* ctx, int chunks);
 /* Row interleave for sharding a pass over several devices/ranks: the rows [row_begin, row_end) of the following runs are
@@ -159,6 +159,10 @@ int selhip_ctx_set_candidate_begin(selhip_ctx* ctx, int64_t k_min);
  *                 bit-serial max, decode tree, population counts; p = 14 only); 0 = on the byte rows with a lane-private LDS
  *                 histogram (hll_union_hist_runs_kernel).  Takes effect at the next upload / attach.
  *   "hist_run"    pairs a wave of stage 2a takes at a time (0 = automatic: 4 on a grouped list; the byte-row kernel: 1, or 4 with the label order);
+ *                 the bit-plane kernel takes at most 64;
+ *   "hist_dense_degree"  bit-plane kernel on a grouped list: from this many survivors per genome (default 32; 0 = always, -1 = never) every
+ *                 XCD walks the whole list and takes the pairs whose candidate row hashes to it, so that its L2 keeps an eighth of the
+ *                 candidate rows instead of streaming all of them (a dense survivor graph: 6.2 -> see DESIGN.md section 4.3);
  *   "hist_blocks" one-wave blocks of the byte-row kernel, "hist_bs_blocks" four-wave blocks of the bit-plane kernel (multiples of 8);
  *   "small_pass"  -1 (default) / 1: a set of up to 2 048 genomes with criterion smh_a takes its whole pass in ONE cooperative launch
  *                 (small_pass_kernel: bounds + signatures, a grid barrier, then join, verification, union histograms and estimator

@@ -166,7 +166,7 @@ def test_row_shards_union_equals_whole(oracle):
 
 
 def test_chunk_lanes_equal_plain(oracle):
-    """row chunks as whole chains on two internal streams (selhip_ctx_set_pipeline; automatic from 1e9 pairs per pass): same
+    """row chunks as whole chains on two internal streams (selhip_ctx_set_pipeline; automatic from 5e8 pairs per pass): same
     pairs, same counters -- smh_a and the two-stage criterion, whole range / sub-range / interleaved parts"""
     cfg = make_golden.GOLDEN_SYNTH["synth_flat_n1000_m256"]
     hll, aux, cards, _, aux_hll = sorted_set(cfg, oracle)
@@ -783,8 +783,10 @@ def test_bitplane_histograms(oracle):
         for algo in (0, 1, -1):
             sel.set_param("hist_algo", algo)
             sel.upload(hll, aux, cards)
-            for run, blocks, label in ((1, 8, 0), (3, 64, 1), (5, 16, 1), (0, 2048, -1)):
+            # (dense 0: every XCD walks the whole list and takes its slice of the candidate rows; -1: never; 32: the default threshold)
+            for run, blocks, label, dense in ((1, 8, 0, -1), (3, 64, 1, 0), (5, 16, 1, 32), (0, 2048, -1, 0), (100, 8, 1, 0), (100, 2048, 1, -1)):
                 sel.set_param("hist_run", run); sel.set_param("hist_bs_blocks", blocks); sel.set_param("group_label", label)
+                sel.set_param("hist_dense_degree", dense)
                 assert_same_pairs(sel.run(0.5, MODE_CB_SMH, r, b), want)
                 assert sel.stats()["survivors"] == st["survivors"]
                 assert_same_pairs(sel.run(0.5, MODE_CB_SMH, r, b, rows=(17, 333)), want[(want["i"] >= 17) & (want["i"] < 333)])
