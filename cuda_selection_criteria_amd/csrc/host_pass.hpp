@@ -572,10 +572,11 @@ hipError_t launch_small_pass(selhip_ctx* c, PassCounters* pc_next, double tau) {
         if (e != hipSuccess) return e;
     }
     u64* barrier_groups = c->small_bar.p;
+    u64 barrier_ticks = c->small_pass == 3 ? 0 : 2000000;                // 20 ms of the 100 MHz wall clock ("small_pass" = 3, test hook: no wait at all)
     double rs = relerr_scaled_for(14);
     selhip_pair_t* results = c->results.p; u64 results_cap = (u64)c->results.cap;
     void* args[] = {&aux, &cards, &bs, &gmax, &n, &m, &r, &nb, &n_pad, &tau, &use_cb, &rm, &cand_begin, &sQ, &sT, &sP, &sG, &ecard, &hi, &pc, &pc_next,
-                    &barrier_word, &barrier_groups, &rs, &results, &results_cap, &fb};
+                    &barrier_word, &barrier_groups, &barrier_ticks, &rs, &results, &results_cap, &fb};
     const unsigned grid = 256;                                           // one block per CU (small_pass_ok checked that the device has 256)
     // an ordinary launch: 256 blocks of 256 threads with 60 KB of LDS and <= 250 registers -- a CU holds two, the device 512 -- all become
     // resident as soon as whatever else is running drains, which is all the kernel's one barrier needs (work of the same stream is over

@@ -26,13 +26,18 @@ constexpr int kSmallBands = 16;              // bands of a candidate's signature
 constexpr int kSmallChunks = 4;              // chunks of 256 candidates a lane has in flight in the join
 constexpr int kSmallQueueCap = kSmallChunks * 256 * kSmallRows;      // flagged candidates awaiting verification: the worst case of one round
 static_assert(kSmallQueueCap >= 64 * 65, "the histogram tile of phase 2 reuses the queue's LDS");
-constexpr u64 kSmallOverflow = ~0ull;        // published in n_pre_segmax of counter block 0 when a block's list overflowed
+constexpr u64 kSmallOverflow = ~0ull;        // published in n_pre_segmax of counter block 0 when a block's list overflowed or its barrier wait ran out
 
 // The grid barrier, two levels: 256 arrivals on ONE word are served one after the other by the memory side (9 us between the last arrival
 // and the release, measured); here a block arrives on its group's word (16 groups, 128 bytes apart), a group's last arrival puts the
 // word back to zero -- ready for the next pass -- and arrives on the top word, which everyone polls.
+// The wait is BOUNDED: an ordinary launch does not promise that all 256 blocks are resident together -- three such kernels of three
+// contexts dispatched at once could each hold a part of the device's 512 block slots and wait for the rest for ever.  A block that has
+// waited `max_ticks` (100 MHz wall clock; 20 ms from the host) gives up: it returns false, the kernel flags the pass for the regular path
+// (as for a list overflow) and ends; every block still arrives exactly once, so the words are left as the next pass needs them.
 constexpr int kSmallBarGroups = 16, kSmallBarStride = 16;                    // (u64 words)
-__device__ __forceinline__ void small_grid_barrier(u64* top, u64* groups, unsigned n_blocks) {
+__device__ __forceinline__ bool small_grid_barrier(u64* top, u64* groups, unsigned n_blocks, u64 max_ticks) {
+    __shared__ int released;
     __syncthreads();
     if (threadIdx.x == 0) {
         __threadfence();
@@ -43,10 +48,17 @@ __device__ __forceinline__ void small_grid_barrier(u64* top, u64* groups, unsign
             atomicExch(gw, 0ull);
             atomicAdd(top, 1ull);
         }
-        while (__hip_atomic_load(top, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (u64)kSmallBarGroups) __builtin_amdgcn_s_sleep(2);
+        const u64 t0 = wall_clock64();
+        int ok = 1;
+        while (__hip_atomic_load(top, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (u64)kSmallBarGroups) {
+            if (wall_clock64() - t0 >= max_ticks) { ok = 0; break; }
+            __builtin_amdgcn_s_sleep(2);
+        }
+        released = ok;
         __threadfence();
     }
     __syncthreads();
+    return released != 0;
 }
 
 #ifdef SELHIP_JOIN_TRACE
@@ -61,7 +73,7 @@ void small_pass_kernel(const u64* __restrict__ aux, const double* __restrict__ c
                        int n, int m, int r, int nb, int n_pad, double tau, int use_cb, RowMap rm, int cand_begin,
                        uint32_t* __restrict__ sigQ, uint32_t* __restrict__ sigT, uint32_t* __restrict__ sigP, uint32_t* __restrict__ sigG,
                        u64* __restrict__ ecard, int* __restrict__ hi, PassCounters* __restrict__ pc, PassCounters* __restrict__ zero_pc,
-                       u64* __restrict__ barrier_word, u64* __restrict__ barrier_groups, double relerr_scaled, selhip_pair_t* __restrict__ results, u64 results_cap, int force_fallback) {
+                       u64* __restrict__ barrier_word, u64* __restrict__ barrier_groups, u64 barrier_ticks, double relerr_scaled, selhip_pair_t* __restrict__ results, u64 results_cap, int force_fallback) {
     __shared__ selhip_int2_t list_lds[kSmallListCap];
     __shared__ uint32_t scratch_lds[kSmallQueueCap];                         // phase 1: flagged (row, band, candidate) triples awaiting
     uint32_t* const counts_lds = scratch_lds;                                // verification; phase 2: 64 pairs' histograms (64 x 65 words)
@@ -89,7 +101,10 @@ void small_pass_kernel(const u64* __restrict__ aux, const double* __restrict__ c
         if (threadIdx.x == 0) { n_list = 0; n_cand_blk = 0; n_queue = 0; }
     }
     SELHIP_SMALL_STAMP(1);
-    small_grid_barrier(barrier_word, barrier_groups, (unsigned)G);
+    if (!small_grid_barrier(barrier_word, barrier_groups, (unsigned)G, barrier_ticks)) {
+        if (threadIdx.x == 0) pc->n_pre_segmax = kSmallOverflow;             // the host repeats the pass on the regular path
+        return;
+    }
     SELHIP_SMALL_STAMP(2);
 
     // ---- phase 1: the block's (up to kSmallRows) query rows against every candidate.  Rows are dealt to the blocks boustrophedon

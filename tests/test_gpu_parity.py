@@ -694,6 +694,19 @@ def test_small_pass_one_launch(oracle):
         assert (got["jaccard"] == got["jaccard"][0]).all()
         got = sel.run(0.9, MODE_SMH, 16, 8)                    # ... and the context remembers
         assert len(got) == n * (n - 1) // 2 and sel.last_attempts() == 1
+    # the grid barrier's wait is bounded (an ordinary launch does not promise that all blocks are resident together): with no patience
+    # at all (test hook) the blocks that are not last give up, the pass is repeated on the regular path, and later passes stay there
+    with Selector(0) as sel:
+        sel.set_param("small_pass", 3)
+        sel.upload(hll2, aux2, cards2)
+        want, st = oracle.select(hll2, aux2, cards2, 0.8, r, b, use_cb=False)
+        for _ in range(3):
+            assert_same_pairs(sel.run(0.8, MODE_SMH, r, b), want)
+            assert sel.get_param("small_pass_used") == 0 and sel.stats()["survivors"] == st["survivors"]
+        sel.set_param("small_pass", 1)                         # (setting the parameter forgets the failure; the barrier words are intact)
+        for _ in range(3):
+            assert_same_pairs(sel.run(0.8, MODE_SMH, r, b), want)
+            assert sel.get_param("small_pass_used") == 1 and sel.stats()["survivors"] == st["survivors"]
 
 
 def test_signature_cache(oracle):
