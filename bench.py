@@ -342,7 +342,7 @@ def main():
                        "pairs_per_step": pairs_per_step, "selected_pairs": int(totals[2].item()),
                        "stage1_survivors": int(totals[1].item()), "n_ranks_seen": n_ranks_seen,
                        "hll_layout": info["layout"], "stage2_grouping": "label order" if info["label"] else "query-row order",
-                       **({"pass": "one cooperative launch (small_pass_kernel)"} if info["small"] else {})},
+                       **({"pass": "one launch (small_pass_kernel)"} if info["small"] else {})},
             "bucket_pair_comparisons_per_s_nominal": value * cfg.m,
             "kernel_ms": kernels,
         }
@@ -357,7 +357,7 @@ def main():
             r1 = join_roofline(pairs_rank0, n_bands, join_q, dom_pass_ms if in_region else detail_ms["join"], launches, dom_span_ms if in_region else -1.0,
                                wkey, "HIP events inside the timed region" if in_region else "HIP events of 5 extra passes after the timed region")
         elif info["small"]:
-            r1 = {"bound": "latency", "kernel": "small_pass_kernel (the whole pass of a set of <= 2 048 genomes in one cooperative launch: bounds + signatures, "
+            r1 = {"bound": "latency", "kernel": "small_pass_kernel (the whole pass of a set of <= 2 048 genomes in one launch: bounds + signatures, "
                                                 "a grid barrier, then join, verification, union histograms and estimator inside each block)",
                   "avg_launch_ms": stage1_ms / launches if stage1_ms > 0 else None, "launches_per_step": launches, "achieved": None, "peak": None,
                   "unit": "n/a", "frac": None, "traffic": None,

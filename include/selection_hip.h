@@ -162,11 +162,13 @@ int selhip_ctx_set_candidate_begin(selhip_ctx* ctx, int64_t k_min);
  *                 the bit-plane kernel takes at most 64;
  *   "hist_dense_degree"  bit-plane kernel on a grouped list: from this many survivors per genome (default 32; 0 = always, -1 = never) every
  *                 XCD walks the whole list and takes the pairs whose candidate row hashes to it, so that its L2 keeps an eighth of the
- *                 candidate rows instead of streaming all of them (a dense survivor graph: 6.2 -> see DESIGN.md section 4.3);
+ *                 candidate rows instead of streaming all of them (a dense survivor graph; bench.py --hard: 6.2 -> 1.5 GB per pass from beyond L2,
+ *                 DESIGN.md section 4.3);
  *   "hist_blocks" one-wave blocks of the byte-row kernel, "hist_bs_blocks" four-wave blocks of the bit-plane kernel (multiples of 8);
- *   "small_pass"  -1 (default) / 1: a set of up to 2 048 genomes with criterion smh_a takes its whole pass in ONE cooperative launch
+ *   "small_pass"  -1 (default) / 1: a set of up to 2 048 genomes with criterion smh_a takes its whole pass in ONE launch
  *                 (small_pass_kernel: bounds + signatures, a grid barrier, then join, verification, union histograms and estimator
- *                 inside each block); 0: the regular chain of launches
+ *                 inside each block; the barrier's wait is bounded and a pass that runs out of patience is repeated on the regular path);
+ *                 2: the same through hipLaunchCooperativeKernel (+15 us per launch); 0: the regular chain of launches
  *   "group_min_n" sets of up to this many genomes (default 2 048) skip the stage-2 grouping: two latency-bound launches that buy nothing
  *                 while the whole table stays in cache; 0 = group always
  *   "group_label" stage-2 grouping lays the query-row buckets out by label = a row's smallest partner, so that the pairs of a

@@ -30,4 +30,25 @@ for wl, n in (("cfg3", None), ("cfg5", 12000)):
         assert np.array_equal(again, ref[0])
         print(wl, "chunks", chunks, "label", label, "ok:", passes, "passes,", st0, flush=True)
     sel.close(); del hll, aux, cards, ah
+# the one-launch pass of a small set (barrier words put back by the kernel itself, barrier top word in the double-buffered counters),
+# alternating with the regular chain and with the dense walk of stage 2a forced on
+cfg = pkg.SYNTH_CONFIGS["cfg2"]
+hll, aux, cards, _, _ = pkg.synth_device(cfg)
+r, b = pkg.banding(cfg.m, cfg.tau)
+sel = pkg.Selector(0); sel.attach(hll, aux, cards)
+ref = None
+for small, dense, mode in ((1, 32, pkg.MODE_SMH), (0, 0, pkg.MODE_SMH), (1, 32, pkg.MODE_CB_SMH), (2, 32, pkg.MODE_SMH)):
+    sel.set_param("small_pass", small); sel.set_param("hist_dense_degree", dense); sel.set_param("group_min_n", 0 if dense == 0 else 2048)
+    first = sel.run(cfg.tau, mode, r, b)
+    st0 = sel.stats()
+    assert sel.get_param("small_pass_used") == (1 if small else 0)
+    if ref is None: ref = first.copy()
+    assert np.array_equal(first, ref)          # (cfg2 is the flat set: CB prunes nothing)
+    for it in range(passes if small != 2 else passes // 10):
+        if it % 7 == 3: sel.run(cfg.tau, mode, r, b, rows=(100, 900), fetch=False)     # another shape of pass in between
+        sel.run(cfg.tau, mode, r, b, fetch=False)
+        assert sel.stats() == st0 and sel.last_attempts() == 1, (small, dense, it, sel.stats(), st0)
+    assert np.array_equal(sel.run(cfg.tau, mode, r, b), ref)
+    print("cfg2 small_pass", small, "dense", dense, "ok:", passes, "passes,", st0, flush=True)
+sel.close()
 print("stress ok")

@@ -56,7 +56,7 @@ if perm:
 sq = [pmc("SQ_INSTS_VALU"), pmc("SQ_LDS_IDX_ACTIVE")]
 names = set(fetch) | set(write) | set(sq[0]) | set(sq[1])
 for k in sorted(names):
-    if not any(s in k for s in ("join", "smh_stream", "hll_union_hist", "hll_bitslice", "verify16", "ertl_select", "sig_build", "aux_fused", "csr_", "stream_interleave")):
+    if not any(s in k for s in ("join", "smh_stream", "hll_union_hist", "hll_bitslice", "verify16", "ertl_select", "sig_build", "aux_fused", "csr_", "stream_interleave", "small_pass")):
         continue
     e = {}
     if k in fetch:

@@ -619,7 +619,7 @@ def test_small_sets_skip_grouping(oracle):
 
 
 def test_small_pass_one_launch(oracle):
-    """sets of up to 2 048 genomes with criterion smh_a take their whole pass in ONE cooperative launch (small_pass_kernel): same pairs,
+    """sets of up to 2 048 genomes with criterion smh_a take their whole pass in ONE launch (small_pass_kernel): same pairs,
     Jaccard bits and counters as the oracle -- and as the regular chain -- for both modes, row ranges, candidate ranges, both FP
     flavours, empty sketches, band shapes with long bands; an overflowing block list falls back to the regular pass"""
     for name, tau in (("synth_flat_n1000_m256", 0.9), ("synth_spread_n600_m64", 0.5), ("synth_flat_n300_m512", 0.5), ("synth_flat_n200_m128", 0.9)):
