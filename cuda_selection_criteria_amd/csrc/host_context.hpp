@@ -129,7 +129,7 @@ struct selhip_ctx {
     DevBuf<int> hll_bs_max;             // largest register value of the set (device side)
     int hll_khi = 0;                    // 0 = no planes; else max register value + 1
     int hist_algo = -1;                 // -1 automatic (bit planes when p = 14), 0 = byte rows + LDS histogram (hll_union_hist_runs_kernel), 1 = bit planes
-    int hist_dense_degree = 32;         // bit-plane kernel: survivors per genome from which a grouped list is walked by candidate slice per XCD (-1 = never)
+    int hist_dense_degree = 32;         // bit-plane kernel: survivors per query row from which a grouped list is walked by candidate slice per XCD (-1 = never)
     int hist_bs_blocks = 2048;          // bit-plane kernel: 4-wave blocks (multiple of 8)
     int group_label = -1;               // grouping: lay the query-row buckets out by label (kernel_hll.cuh): -1 = automatic (HLL rows beyond kLabelOrderBytes), 0 off, 1 on
     int verify_fb = 0;                  // test hook: force the collision fallback of verify16_kernel

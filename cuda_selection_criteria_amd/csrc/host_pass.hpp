@@ -494,7 +494,10 @@ int enqueue_tail(selhip_ctx* c, const Chain& ch, const selhip_int2_t* final_list
                 HIPCHK(&c->err, launch_hist_bs(c->hll_khi, (unsigned)c->hist_bs_blocks, st, c->hll_bs.p, c->hll_gmax.p, final_list, final_count, final_cap, ch.counts, off, ch.window,
                                                c->hist_run > 0 ? c->hist_run : (grouped ? 4 : 1),
                                                // a dense survivor graph is walked by candidate-row slice per XCD (query-major list only)
-                                               grouped && c->hist_dense_degree >= 0 ? (u64)c->hist_dense_degree * (u64)c->n : ~0ull));
+                                               // ("dense" = survivors per QUERY ROW of this chain: a rank's or a lane's share of the rows sees
+                                               //  its share of the pairs and all of the candidate rows)
+                                               grouped && c->hist_dense_degree >= 0
+                                                   ? (u64)c->hist_dense_degree * (u64)std::max<long long>(1, ((long long)ch.re - ch.rb) / std::max(1, c->il_parts)) : ~0ull));
             else if (c->p == 14)
                 hipLaunchKernelGGL(hll_union_hist_runs_kernel, dim3(c->hist_blocks), dim3(kWave), (size_t)c->hist_pad, st,
                                    c->d_hll, final_list, final_count, final_cap, ch.counts, off, ch.window,

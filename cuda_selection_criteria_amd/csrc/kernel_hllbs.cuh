@@ -241,7 +241,7 @@ void hll_union_hist_bs_kernel(const uint32_t* __restrict__ bs, const uint8_t* __
     pairs += chunk_off;
     const u64 stride = (u64)(gridDim.x >> 3) * kWavesPerBlock;            // waves per XCD (the host launches a multiple of 8 blocks)
     const int my_bin = ((lane & 2) ? 32 : 0) + 2 * bs_pidx(lane) + (lane & 1);
-    // A DENSE survivor graph (n_pairs >= dense_pairs; the host sets 32 pairs per genome on a grouped list, "hist_dense_degree"): a query
+    // A DENSE survivor graph (n_pairs >= dense_pairs; the host sets 32 pairs per query row of the pass on a grouped list, "hist_dense_degree"): a query
     // row has tens to hundreds of partners spread over the whole table, the table does not fit one L2 (4 MiB = ~400 rows) and in list
     // order every pair fetches its candidate row from beyond it (the 25 %-degenerate set of bench.py: 730 000 pairs among 2 516 genomes,
     // 6.2 GB per pass at 92 % of the Infinity Cache's gather rate).  Then every XCD walks the WHOLE list, 64 pairs per task, and takes

@@ -160,7 +160,7 @@ int selhip_ctx_set_candidate_begin(selhip_ctx* ctx, int64_t k_min);
  *                 histogram (hll_union_hist_runs_kernel).  Takes effect at the next upload / attach.
  *   "hist_run"    pairs a wave of stage 2a takes at a time (0 = automatic: 4 on a grouped list; the byte-row kernel: 1, or 4 with the label order);
  *                 the bit-plane kernel takes at most 64;
- *   "hist_dense_degree"  bit-plane kernel on a grouped list: from this many survivors per genome (default 32; 0 = always, -1 = never) every
+ *   "hist_dense_degree"  bit-plane kernel on a grouped list: from this many survivors per query row of the pass (default 32; 0 = always, -1 = never) every
  *                 XCD walks the whole list and takes the pairs whose candidate row hashes to it, so that its L2 keeps an eighth of the
  *                 candidate rows instead of streaming all of them (a dense survivor graph; bench.py --hard: 6.2 -> 1.5 GB per pass from beyond L2,
  *                 DESIGN.md section 4.3);

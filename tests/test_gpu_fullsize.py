@@ -38,6 +38,45 @@ def test_baseline_configs_bit_exact_vs_oracle(oracle, key):
                 assert s["evaluated"] == st["evaluated"] and s["survivors"] == st["survivors"]
             if key == "cfg3" and not use_cb:
                 assert st["evaluated"] == 49_995_000 and len(want) == 45_000               # 1000 clusters x C(10,2)
+            if key == "cfg2":                    # configs[1] is the size the one-launch pass exists for (the suite's default switches it off)
+                sel.set_param("small_pass", -1)
+                got = sel.run(cfg.tau, mode, r, b)
+                assert sel.get_param("small_pass_used") == 1 and same(got, want)
+                s = sel.stats()
+                assert s["evaluated"] == st["evaluated"] and s["survivors"] == st["survivors"]
+                sel.set_param("small_pass", 0)
+
+
+def test_dense_survivor_graph_full_size():
+    """bench.py's harder workload at its size (configs[2] with a quarter of the genomes degenerate: ~730 000 stage-1 survivors among
+    2 516 genomes, 290 partners per row): stage 2a walks such a list by candidate-row slice per XCD ("hist_dense_degree").  Too many
+    union cardinalities for the oracle to finish in seconds, so: the dense walk == the list-order walk == the byte-row LDS kernel (an
+    independent stage 2a: no bit planes, no slices), pairs, Jaccard bits and counters; and the same again on one of 8 interleaved row
+    shares, where the threshold counts the share's rows"""
+    cfg = pkg.SYNTH_CONFIGS["cfg3"]
+    hll_t, aux_t, cards_t, _, _ = pkg.synth_device(cfg)
+    n_deg = pkg.harden(aux_t)
+    assert 2000 < n_deg < 3000
+    r, b = pkg.banding(cfg.m, cfg.tau)
+    with Selector(0) as sel:
+        sel.attach(hll_t, aux_t, cards_t)
+        for shard in (None, (128, 8, 3)):
+            if shard: sel.set_row_interleave(*shard)
+            ref = None
+            for dense, algo in ((32, 1), (-1, 1), (0, 1), (32, 0)):
+                sel.set_param("hist_dense_degree", dense)
+                if algo == 0 or ref is None:
+                    sel.set_param("hist_algo", algo); sel.attach(hll_t, aux_t, cards_t)        # (takes effect at attach)
+                got = sel.run(cfg.tau, MODE_SMH, r, b)
+                st = sel.stats()
+                if ref is None:
+                    ref = (got.copy(), st)
+                    assert st["survivors"] > (600_000 if not shard else 60_000) and 0 < len(got) < st["survivors"]
+                assert st == ref[1], (shard, dense, algo, st, ref[1])
+                assert np.array_equal(got["i"], ref[0]["i"]) and np.array_equal(got["k"], ref[0]["k"])
+                assert np.array_equal(got["jaccard"].view(np.uint64), ref[0]["jaccard"].view(np.uint64))
+            sel.set_param("hist_algo", 1)
+        sel.set_row_interleave(0, 1, 0)
 
 
 def test_grouping_scan_in_lds_above_64k(oracle):
