@@ -140,6 +140,9 @@ struct selhip_ctx {
     int join_bits = 16;                 // signature width of the all-pairs join: 16 (packed min), 15 (LDS form only: flag arithmetic, all plain VOP2) or 32
     int join_q = 1;                     // 16-bit join, query side: 1 = tile staged in LDS, broadcast reads (sigl_join_kernel), 0 = DPP row broadcast (sig16_join_kernel)
     long long enum_pairs = kEnumPairs;  // hll_a / hll_an as first criterion: pairs listed per sub-pass (test hook "enum_pairs")
+    // genomes per tile of the tiled signature build ("sig_tile_g": 8 / 16 / 32).  Measured, build alone, 8 / 16 / 32: cfg3 15.9 / 16.4 / 21.3 us,
+    // 28 280 genomes 36.9 / 35.0 / 42.2, cfg4 64.5 / 60.4 / 67.2 (gpurun_out/r03/o_*): full 128-byte band-major segments (32) do not pay
+    int sig_tile_g = 16;
     int sig_cache = 0;                  // keep the band signatures across passes ("sig_cache"); sig_key = what the arrays hold (0 = nothing)
     long long sig_key = 0;
     int sig_tile = 1;                   // signature build: tiled form (0 = one thread per bucket, the round-1 kernel)

@@ -191,7 +191,8 @@ hipError_t launch_sig_build(selhip_ctx* c, int n_rows, int n_bands, bool with_bo
     // signature arrays invalidate them.  The bounds blocks still run every pass (they depend on tau, the mode and the rows).
     const long long sig_key = ((long long)n_rows << 40) | ((long long)n_bands << 20) | ((long long)(c->join_bits == 15) << 2) | (tile_mode ? 2 : 0) | 1;
     const bool cached = c->sig_cache && c->sig_key == sig_key && with_bounds;
-    const unsigned work_blocks = cached ? 0u : tile_mode ? (unsigned)((n + kSigTileG - 1) / kSigTileG) : (unsigned)((threads + kBlock - 1) / kBlock);
+    const int tg = c->sig_tile_g;                                       // genomes per tile
+    const unsigned work_blocks = cached ? 0u : tile_mode ? (unsigned)((n + tg - 1) / tg) : (unsigned)((threads + kBlock - 1) / kBlock);
     c->sig_key = c->sig_cache ? sig_key : 0;
     if (work_blocks + (unsigned)bounds_blocks == 0) return hipSuccess;
     hipLaunchKernelGGL(sig_build_kernel, dim3(work_blocks + (unsigned)bounds_blocks), dim3(kBlock), 0, c->stream,
@@ -199,7 +200,7 @@ hipError_t launch_sig_build(selhip_ctx* c, int n_rows, int n_bands, bool with_bo
                        bounds_blocks, c->d_cards, tau, c->mode == SELHIP_MODE_CB_SMH ? 1 : 0, row_map(c, rb, re), c->ecard.p, c->hi.p, c->pcb,
                        grouping_on(c) ? c->csr_cnt.p : nullptr, grouping_on(c) ? (int)c->csr_cnt.cap : 0, (int)c->cand_begin,
                        with_bounds ? c->seg_cnt.p : nullptr, with_bounds ? (int)c->seg_cnt.cap : 0, c->join_bits == 15 ? 17 : 16,
-                       zero_pc, tile_mode ? 1 : 0);
+                       zero_pc, tile_mode ? tg : 0);
     return hipGetLastError();
 }
 

@@ -97,15 +97,16 @@ __device__ __forceinline__ void sig_build_body(long long block, const u64* __res
 //    [genome][band], from which all four layouts are written in full segments: sigQ / sigG rows contiguous, sigT / sigP as
 //    kSigTileG consecutive genomes per band (the per-genome form wrote each band-major entry as a lone 4-byte store: 19.5 MB
 //    of HBM writes for 7.7 MB of signatures, PMC WRITE_SIZE).
-constexpr int kSigTileG = 16;
+constexpr int kSigTileG = 32;             // LDS capacity of a tile; the launch says how many genomes a tile holds (16 by default)
 
+template <int CAP>
 __device__ __forceinline__ void sig_build_tile_body(int tile, const u64* __restrict__ aux, int n, int m, int r, int nb, int n_pad,
                                                     uint32_t* __restrict__ sigQ, uint32_t* __restrict__ sigT, uint32_t* __restrict__ sigP,
                                                     uint32_t* __restrict__ sigG, int pk_shift,
-                                                    int tg = kSigTileG, bool all_layouts = true) {
-    // (tg <= kSigTileG genomes per tile: the one-launch pass of a small set spreads ITS genomes over all its blocks; it only reads the
+                                                    int tg, bool all_layouts = true) {
+    // (tg <= CAP genomes per tile: the one-launch pass of a small set spreads ITS genomes over all its blocks; it only reads the
     //  32-bit layouts sigQ / sigT and leaves the packed ones alone)
-    __shared__ uint32_t sig_lds[kSigTileG][129];                          // pitch 129: the band-major read-out is conflict-free
+    __shared__ uint32_t sig_lds[CAP][129];                          // pitch 129: the band-major read-out is conflict-free
     const int g0 = tile * tg;
     const int ng = min(tg, n - g0);
     if (ng <= 0) return;
@@ -167,6 +168,7 @@ void sig_build_kernel(const u64* __restrict__ aux, int n, int m, int r, int nb, 
                       int bounds_blocks, const double* __restrict__ cards, double tau, int use_cb, RowMap rm,
                       u64* __restrict__ ecard, int* __restrict__ hi, PassCounters* __restrict__ pc, int* __restrict__ csr_zero, int csr_zero_n, int cand_begin,
                       u64* __restrict__ seg_zero, int seg_zero_n, int pk_shift, PassCounters* __restrict__ zero_pc, int tile_mode) {
+    // (tile_mode = genomes per tile of the tiled build, 0 = the per-bucket form)
     if ((int)blockIdx.x < bounds_blocks) {
         const int t = (int)(blockIdx.x * kBlock + threadIdx.x);
         zero_next_counters(t, bounds_blocks * kBlock, zero_pc, kCounterBlocks);
@@ -175,7 +177,7 @@ void sig_build_kernel(const u64* __restrict__ aux, int n, int m, int r, int nb, 
         cb_bounds_body(t, cards, n, tau, use_cb, rm, ecard, hi, pc, cand_begin);
         return;
     }
-    if (tile_mode) sig_build_tile_body((int)blockIdx.x - bounds_blocks, aux, n, m, r, nb, n_pad, sigQ, sigT, sigP, sigG, pk_shift);
+    if (tile_mode) sig_build_tile_body<kSigTileG>((int)blockIdx.x - bounds_blocks, aux, n, m, r, nb, n_pad, sigQ, sigT, sigP, sigG, pk_shift, tile_mode);
     else           sig_build_body((long long)blockIdx.x - bounds_blocks, aux, n, m, r, nb, n_pad, sigQ, sigT, sigP, sigG, pk_shift);
 }
 

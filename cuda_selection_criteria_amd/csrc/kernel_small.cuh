@@ -97,7 +97,7 @@ void small_pass_kernel(const u64* __restrict__ aux, const double* __restrict__ c
         if (lane == 0 && ev > 0) atomicAdd(&pc->n_evaluated, (u64)ev);
         // the signatures, every block its (n + G - 1) / G genomes (<= 8): one load round trip instead of the four a 16-genome tile takes
         const int tg = (n + G - 1) / G;
-        sig_build_tile_body((int)blockIdx.x, aux, n, m, r, nb, n_pad, sigQ, sigT, sigP, sigG, 16, tg, false);
+        sig_build_tile_body<kSmallRows>((int)blockIdx.x, aux, n, m, r, nb, n_pad, sigQ, sigT, sigP, sigG, 16, tg, false);
         if (threadIdx.x == 0) { n_list = 0; n_cand_blk = 0; n_queue = 0; }
     }
     SELHIP_SMALL_STAMP(1);
