@@ -99,6 +99,9 @@ __device__ __forceinline__ void sig_build_body(long long block, const u64* __res
 //    of HBM writes for 7.7 MB of signatures, PMC WRITE_SIZE).
 constexpr int kSigTileG = 32;             // LDS capacity of a tile; the launch says how many genomes a tile holds (16 by default)
 
+// 16-byte loads a thread has in flight (8 and 16 measured no better: build alone 17.3 / 17.5 / 18.9 us at cfg3, 60.4 / 60.1 / 63.0 at cfg4,
+// gpurun_out/r03/p_*)
+constexpr int kSigLoads = 4;
 template <int CAP>
 __device__ __forceinline__ void sig_build_tile_body(int tile, const u64* __restrict__ aux, int n, int m, int r, int nb, int n_pad,
                                                     uint32_t* __restrict__ sigQ, uint32_t* __restrict__ sigT, uint32_t* __restrict__ sigP,
@@ -115,15 +118,15 @@ __device__ __forceinline__ void sig_build_tile_body(int tile, const u64* __restr
     const int total = ng * half_m;                                        // bucket pairs of this tile
     const u64x2* src = reinterpret_cast<const u64x2*>(aux + (size_t)g0 * m);
     const int L = r >> 1;                                                 // lanes per band (1..16)
-    for (int base = 0; base < total; base += 4 * kBlock) {
-        u64x2 v[4];
+    for (int base = 0; base < total; base += kSigLoads * kBlock) {
+        u64x2 v[kSigLoads];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < kSigLoads; ++u) {
             const int idx = base + u * kBlock + (int)threadIdx.x;
             v[u] = idx < total ? src[idx] : u64x2{0, 0};
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < kSigLoads; ++u) {
             const int idx = base + u * kBlock + (int)threadIdx.x;         // blocks of 256 pairs never straddle a band (L <= 16 divides 256)
             const int bucket = (idx << 1) & (m - 1);
             const int j = bucket & (r - 1);                               // position of the first of the two buckets inside its band
