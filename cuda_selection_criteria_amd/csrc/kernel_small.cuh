@@ -136,6 +136,8 @@ void small_pass_kernel(const u64* __restrict__ aux, const double* __restrict__ c
     int hreg = -1;
     if ((int)threadIdx.x < nr) hreg = hi[row_of((int)threadIdx.x)];
     bool parked = false;
+    const __amdgpu_buffer_rsrc_t sigT_rsrc = __builtin_amdgcn_make_buffer_rsrc(sigT, 0, nb * n_pad * 4, 0x00020000);
+    const int row_bytes = n_pad * 4;
     if (nr > 0) {
         const int k_first = (max(row_of(0) + 1, z0) / kBlock) * kBlock;
         for (int k0 = k_first; k0 < n; k0 += kSmallChunks * kBlock) {
@@ -148,12 +150,17 @@ void small_pass_kernel(const u64* __restrict__ aux, const double* __restrict__ c
 #pragma unroll
                 for (int ri = 0; ri < kSmallRows; ++ri) fband[c][ri] = kSmallNoBand;
             for (int b0 = 0; b0 < nb; b0 += kSmallBands) {                    // (nb is 8 or a multiple of 16: sig_supported)
+                // (through a buffer resource: the band's row rides in the scalar offset, the lane's column in the 32-bit vector offset --
+                //  guarded 64-bit addressing put two branches and a 64-bit multiply around every one of these 64 loads.  Columns past
+                //  the last genome and bands past the last band are clamped: such a value is never compared (bands) or never a hit
+                //  (columns: `k < n` below))
                 uint32_t cv[kSmallChunks][kSmallBands];
 #pragma unroll
                 for (int c = 0; c < kSmallChunks; ++c) {
-                    const int k = k0 + c * kBlock + (int)threadIdx.x;
+                    const int kk = min(k0 + c * kBlock + (int)threadIdx.x, n_pad - 1) * 4;
 #pragma unroll
-                    for (int u = 0; u < kSmallBands; ++u) cv[c][u] = (k < n && b0 + u < nb) ? sigT[(size_t)(b0 + u) * n_pad + k] : 0u;
+                    for (int u = 0; u < kSmallBands; ++u)
+                        cv[c][u] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(sigT_rsrc, kk, min(b0 + u, nb - 1) * row_bytes, 0);
                 }
                 if (!parked) {                                                // block-uniform
                     parked = true;
