@@ -21,9 +21,10 @@ n_sets = n_runs = 0
 while time.time() < t_end:
     n = int(rng.choice([2, 3, 17, 64, 65, 130, 257, 600, 1025, 2048, 2049, 2500]))
     m = int(rng.choice([64, 128, 256, 512]))
-    cfg = SynthConfig("fuzz", n, m, 0.8, int(rng.integers(1, 1 << 30)), cluster_size=int(rng.choice([2, 5, 10, 40])), mode=int(rng.integers(0, 2)),
-                      n_sh_lo=2000, n_sh_hi=int(rng.choice([2000, 20000])))
-    hll, aux, _ = pkg.synth_host(cfg)
+    with_aux = rng.random() < 0.35 and n <= 700           # (hll_a / hll_an as FIRST criterion run the estimator on every pair)
+    cfg = SynthConfig("fuzz", n, m, 0.8, int(rng.integers(1, 1 << 30)), p_aux=8 if with_aux else 0, cluster_size=int(rng.choice([2, 5, 10, 40])),
+                      mode=int(rng.integers(0, 2)), n_sh_lo=2000, n_sh_hi=int(rng.choice([2000, 20000])))
+    hll, aux, aux_hll = pkg.synth_host(cfg)
     if rng.random() < 0.4: pkg.harden(aux, frac=float(rng.choice([0.1, 0.5, 1.0])) if n < 1000 else 0.1, seed=int(rng.integers(1, 1 << 30)))
     if rng.random() < 0.3 and n > 8: hll[: int(rng.integers(1, 4))] = 0
     if rng.random() < 0.3 and n > 8:
@@ -31,10 +32,12 @@ while time.time() < t_end:
     cards = orc.cards(hll)
     perm = pkg.sort_by_card(cards)
     hll, aux, cards = hll[perm], aux[perm], cards[perm]
+    if with_aux: aux_hll = aux_hll[perm]
     n_sets += 1
     with pkg.Selector(0) as sel:
         sel.set_param("init_cap", int(rng.choice([1024, 1 << 20])))
         sel.upload(hll, aux, cards)
+        if with_aux: sel.upload_aux_hll(aux_hll, 8)
         for _ in range(6):
             tau = float(rng.choice([0.3, 0.5, 0.8, 0.9, 0.95]))
             if rng.random() < 0.6: r, b = pkg.banding(m, tau)
@@ -46,7 +49,10 @@ while time.time() < t_end:
                       "join_bits": int(rng.choice([16, 16, 15, 32])), "sig_cache": int(rng.integers(0, 2)), "hist_bs_blocks": int(rng.choice([8, 64, 2048]))}
             for k, v in params.items(): sel.set_param(k, v)
             sel.set_pipeline(int(rng.choice([-1, 0, 2, 3])))
-            want, st = orc.select(hll, aux, cards, tau, r, b, use_cb=use_cb)
+            crit = int(rng.choice([pkg.CRIT_SMH_A, pkg.CRIT_HLL_A, pkg.CRIT_HLL_AN, pkg.CRIT_HLL_A_SMH_A])) if with_aux else pkg.CRIT_SMH_A
+            sel.set_criterion(crit)
+            params["crit"] = crit
+            want, st = orc.select(hll, aux, cards, tau, r, b, use_cb=use_cb, criterion=crit, aux_hll=aux_hll if with_aux else None, p_aux=8)
             mode = pkg.MODE_CB_SMH if use_cb else pkg.MODE_SMH
             kind = rng.integers(0, 4)
             ctx = (n, m, cfg.seed, tau, r, b, use_cb, params, int(kind))
