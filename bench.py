@@ -14,7 +14,7 @@ Workloads
                         BASELINE.json configs[3]: 50 000 genomes, m=512, the SAME 1.25e9 pairs sharded over
                         the N GPUs ("scaling": "strong") -- the second scaling line.
   --workload cfg5 [--scaling strong]   configs[4]: 100 000 genomes, hll_a(p=8) prefilter + smh_a m=1024.
-The pair space is sharded by query rows: interleaved blocks of 128 rows, block b on rank b mod N; every rank holds a
+The pair space is sharded by query rows: interleaved blocks of 128 rows dealt to the ranks boustrophedon (0 .. N-1, N-1 .. 0, ...); every rank holds a
 full replica of the sketches.
 
 `python bench.py --gpus N` with N > 1 and no torch.distributed environment starts its own ranks: it runs
@@ -172,7 +172,7 @@ def main():
         name, _, val = kv.partition("=")
         sel.set_param(name, int(val))
     if world > 1:
-        # shard the pair space by interleaved blocks of query rows: rank r owns the blocks b with b % world == r, i.e. an
+        # shard the pair space by interleaved blocks of query rows, dealt boustrophedon (csrc/common.cuh, RowMap), i.e. an
         # equal share of the pairs AND of the survivors (stage 2) -- a contiguous equal-pair cut would leave the last rank
         # with a third of all rows, hence of all stage-2 work
         sel.set_row_interleave(IL_BLOCK, world, rank)

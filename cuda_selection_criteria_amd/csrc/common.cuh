@@ -40,26 +40,33 @@ static_assert(sizeof(PassCounters) % 8 == 0, "counter blocks are cleared and cop
 
 
 // ---------------------------------------------------------------------------------------------
-// RowMap: which query rows a pass owns.  Rows [row_begin, row_end) are cut into blocks of block_rows rows; the pass owns
-// the blocks b with b % n_parts == part.  n_parts = 1 (one block spanning the range) is the plain contiguous range; the
-// multi-GPU drivers use n_parts = world size with small blocks, so that every rank gets the same share of pairs AND of
-// survivors (a contiguous equal-pair cut gives the last rank ~35 % of all rows, hence of all stage-2 work, at 8 ranks).
+// RowMap: which query rows a pass owns.  Rows [row_begin, row_end) are cut into blocks of block_rows rows, dealt to the n_parts
+// parts BOUSTROPHEDON: cycle q (blocks q n_parts .. (q + 1) n_parts - 1) hands its r-th block to part r when q is even and to part
+// n_parts - 1 - r when q is odd.  Row i has n - 1 - i candidates, so under the plain deal (block b to part b % n_parts) part 0 always
+// got the longest rows of a cycle: 51.6e6 pairs against 48.4e6 for part 7 of 8 at 28 280 genomes, and the slowest rank sets the step
+// (0.262 ms against a mean of 0.243, profiles/r03_scaling_emulation.txt); the snake evens that out to second order.
+// n_parts = 1 (one block spanning the range) is the plain contiguous range; the multi-GPU drivers use n_parts = world size with
+// small blocks, so that every rank gets the same share of pairs AND of survivors (a contiguous equal-pair cut gives the last rank
+// ~35 % of all rows, hence of all stage-2 work, at 8 ranks).
 // Kernels address their query rows through "local tiles": tile t of height tile_h inside the owned blocks.
 // ---------------------------------------------------------------------------------------------
 struct RowMap {
     int row_begin, row_end, block_rows, n_parts, part;
     __host__ __device__ int total_blocks() const { return (int)(((long long)row_end - row_begin + block_rows - 1) / block_rows); }
-    __host__ __device__ int local_blocks() const { const int tb = total_blocks(); return part < tb ? (tb - part + n_parts - 1) / n_parts : 0; }
+    __host__ __device__ int pos_in_cycle(int q) const { return (q & 1) ? n_parts - 1 - part : part; }     // this part's block inside cycle q
+    __host__ __device__ int local_blocks() const { const int tb = total_blocks(), full = tb / n_parts; return full + (pos_in_cycle(full) < tb % n_parts ? 1 : 0); }
     __host__ __device__ int tiles_per_block(int tile_h) const { return (block_rows + tile_h - 1) / tile_h; }
     __host__ __device__ long long n_tiles(int tile_h) const { return (long long)local_blocks() * tiles_per_block(tile_h); }
     __host__ __device__ bool owns(int i) const {
-        return i >= row_begin && i < row_end && ((i - row_begin) / block_rows) % n_parts == part;
+        if (i < row_begin || i >= row_end) return false;
+        const int b = (i - row_begin) / block_rows;
+        return b % n_parts == pos_in_cycle(b / n_parts);
     }
     // rows [*lo, *end) of local tile t; empty (lo == end) past the range
     __device__ __forceinline__ void tile_rows(int t, int tile_h, int* lo, int* end) const {
         const int tpb = tiles_per_block(tile_h);
         const int lb = t / tpb, w = t % tpb;
-        const long long bs = (long long)row_begin + ((long long)lb * n_parts + part) * block_rows;
+        const long long bs = (long long)row_begin + ((long long)lb * n_parts + pos_in_cycle(lb)) * block_rows;     // one block per cycle
         long long l = bs + (long long)w * tile_h;
         long long e = l + tile_h;
         if (e > bs + block_rows) e = bs + block_rows;

@@ -370,6 +370,9 @@ hipError_t launch_aux_fused(selhip_ctx* c, hipStream_t st, const selhip_int2_t* 
 }
 
 // equal-pair row boundaries of the triangle rows [rb, re) x columns (row, n): the same cut the multi-GPU drivers use
+// rows after which the deal of the row interleave repeats: two cycles of n_parts blocks (the snake turns round every cycle)
+long long interleave_period(const selhip_ctx* c) { return c->il_parts > 1 ? 2ll * c->il_block * c->il_parts : 1; }
+
 void chunk_rows(long long n, long long rb, long long re, int chunks, long long period, long long* bnd) {
     // boundaries fall on whole interleave periods counted from rb (row ownership is defined relative to the range's first row)
     const double total = (double)pair_bound(n, rb, re);
@@ -697,7 +700,7 @@ int enqueue_pass(selhip_ctx* c) {
         // contexts on two streams before it was built (scripts/overlap_probe.py): cfg4 on one of 8 ranks 0.551 -> 0.544 ms even with
         // the signature build done twice.
         long long bnd[kMaxChunks + 1];
-        chunk_rows(n, rb, re, chunks, c->il_parts > 1 ? (long long)c->il_block * c->il_parts : 1, bnd);
+        chunk_rows(n, rb, re, chunks, interleave_period(c), bnd);
         // lane 0 is the context's own stream (cross-stream waits cost ~10 us each: one to start lane 1, one to join it).
         // (Staggering the lanes -- chunk k's join waits for chunk k-1's join, so that every tail runs beside the NEXT join and only the
         // last tail is exposed -- was measured: cfg4 2.78 vs 2.73 ms, cfg5 9.79 vs 9.74 ms with 2 chunks, no better with 4: the tail
@@ -730,7 +733,7 @@ int enqueue_pass(selhip_ctx* c) {
         // more than 2^28 pairs per call).  Sub-range boundaries fall on whole interleave periods so that row ownership
         // (RowMap blocks are counted from the range's first row) is the same as for the whole range.
         const StageIO& io = ch.io;
-        const long long period = c->il_parts > 1 ? (long long)c->il_block * c->il_parts : 1;
+        const long long period = interleave_period(c);
         long long sb = rb;
         while (sb < re) {
             long long se = sb;
@@ -793,7 +796,7 @@ int ensure_scratch(selhip_ctx* c, size_t surv_cap, size_t res_cap) {
     if (c->criterion == SELHIP_CRIT_HLL_A || c->criterion == SELHIP_CRIT_HLL_AN) {
         // the explicit pair space is materialised kEnumPairs pairs at a time (8 B per pair); one interleave period of rows is the
         // smallest unit, so the buffer holds at least that
-        const long long period = c->il_parts > 1 ? (long long)c->il_block * c->il_parts : 1;
+        const long long period = interleave_period(c);
         long long unit = 0;
         for (long long s = c->row_begin; s < c->row_end; s += period) unit = std::max(unit, pair_bound(c->n, s, std::min<long long>(c->row_end, s + period)));
         const long long bound = std::min(pair_bound(c->n, c->row_begin, c->row_end), std::max(c->enum_pairs, unit));

@@ -1,8 +1,8 @@
 """Multi-GPU layer: one process per GPU (torch.distributed; backend "nccl" = RCCL over xGMI on the
 GPU box, "gloo" in CPU tests).  The pair space shards naturally -- every pair is independent given
 read-only sketches -- so each rank holds a full replica of the sketches and evaluates
-the query rows it owns.  Ownership is an INTERLEAVE: rows are cut into blocks of `block` rows (128) and block b
-belongs to rank b mod world (selhip_ctx_set_row_interleave; `interleave_owner` below) -- every rank then gets the
+the query rows it owns.  Ownership is an INTERLEAVE: rows are cut into blocks of `block` rows (128), dealt to the ranks
+boustrophedon -- 0 .. world-1, then world-1 .. 0, and so on (selhip_ctx_set_row_interleave; `interleave_owner` below) -- every rank then gets the
 same share of pairs AND of survivors whatever the shape of the (triangular or CB-banded) pair space; the
 contiguous equal-pair cut (`shard_rows`, libselhost selhost_shard_rows) stays for callers that want row ranges.
 The only exchange step is the gather of the selected-pair lists.  No collective touches the sketch data path."""
@@ -41,8 +41,11 @@ def cb_bounds(cards: np.ndarray, tau: float) -> np.ndarray:
 
 
 def interleave_owner(rows, block: int, world: int):
-    """rank that owns query row(s) `rows` under the row interleave (block b -> rank b mod world)"""
-    return (np.asarray(rows, dtype=np.int64) // block) % world
+    """rank that owns query row(s) `rows` under the row interleave: blocks are dealt boustrophedon, block b = q * world + r goes to
+    rank r in even cycles q and to rank world - 1 - r in odd ones (csrc/common.cuh, RowMap)"""
+    b = np.asarray(rows, dtype=np.int64) // block
+    q, r = b // world, b % world
+    return np.where(q & 1, world - 1 - r, r)
 
 
 def interleave_pair_counts(n: int, block: int, world: int, hi: Optional[np.ndarray] = None, z0: int = 0) -> np.ndarray:

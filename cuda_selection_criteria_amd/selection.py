@@ -199,7 +199,8 @@ class Selector:
         check(self._lib.selhip_ctx_set_pipeline(self._ctx, chunks), self._ctx)
 
     def set_row_interleave(self, block_rows: int, n_parts: int, part: int):
-        """the following runs evaluate only the row blocks b (of block_rows rows) with b % n_parts == part"""
+        """the following runs evaluate only this part's row blocks (of block_rows rows, dealt to the n_parts parts boustrophedon:
+        distributed.interleave_owner)"""
         check(self._lib.selhip_ctx_set_row_interleave(self._ctx, block_rows, n_parts, part), self._ctx)
 
     def set_candidate_begin(self, k_min: int):

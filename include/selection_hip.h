@@ -129,9 +129,11 @@ int selhip_ctx_set_stream(selhip_ctx* ctx, void* hip_stream);
  * count.  Results and counters do not depend on it.  (Round 1's stage-1-stream / stage-2-stream pipeline was replaced.) */
 int selhip_ctx_set_pipeline(selhip_ctx* ctx, int chunks);
 /* Row interleave for sharding a pass over several devices/ranks: the rows [row_begin, row_end) of the following runs are
- * cut into blocks of block_rows rows (a multiple of 32) and the run evaluates only the blocks b with b % n_parts == part.
- * Every rank then gets the same share of the pair space AND of the survivors, whatever the triangle's shape (a contiguous
- * equal-pair cut hands the last of 8 ranks ~35 % of all rows, i.e. of all stage-2 work).  n_parts <= 1 switches it off. */
+ * cut into blocks of block_rows rows (a multiple of 32), dealt boustrophedon: of the n_parts blocks of cycle q the run evaluates
+ * block number `part` when q is even and block number n_parts - 1 - part when q is odd (rows get shorter towards the end of the
+ * triangle, so a plain round-robin deal would give part 0 the longest row block of every cycle).  Every rank then gets the
+ * same share of the pair space AND of the survivors, whatever the triangle's shape (a contiguous equal-pair cut hands the
+ * last of 8 ranks ~35 % of all rows, i.e. of all stage-2 work).  n_parts <= 1 switches it off. */
 int selhip_ctx_set_row_interleave(selhip_ctx* ctx, int block_rows, int n_parts, int part);
 /* Rectangular passes: the following runs only take candidates k >= k_min (in addition to k > i), i.e. rows [row_begin,
  * row_end) x columns [k_min, n).  With the uploaded array = block I followed by block J of a larger sorted set,

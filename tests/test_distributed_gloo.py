@@ -1,6 +1,6 @@
 """N>1 path on CPU: world_size-2 gloo.  The GPU compute is replaced by the CPU oracle as a stand-in producer (this is a
 test of the partition + gather logic in cuda_selection_criteria_amd/distributed.py, which is backend-agnostic).  Rows are
-dealt out the way the product deals them -- interleaved blocks of 128 rows, block b on rank b mod world
+dealt out the way the product deals them -- interleaved blocks of 128 rows, dealt to the ranks boustrophedon
 (selhip_ctx_set_row_interleave) -- and the union of the shards must equal the single-rank answer, with no duplicates and
 every record on the rank that owns its row.  The GPU side of the same partition (Selector.set_row_interleave, parts 0..P-1 on
 one device tile the full result and its statistics) is tests/test_gpu_parity.py::test_interleaved_row_blocks_tile_the_pair_space."""

@@ -15,6 +15,7 @@ pytestmark = pytest.mark.gpu
 import cuda_selection_criteria_amd as pkg  # noqa: E402
 from cuda_selection_criteria_amd import (ALGO_AUTO, ALGO_HASHJOIN, ALGO_SIG, ALGO_STREAM, FP_FMA, FP_STRICT, MODE_CB_SMH, MODE_SMH, Selector)  # noqa: E402
 from cuda_selection_criteria_amd.synth import SynthConfig  # noqa: E402
+from cuda_selection_criteria_amd import distributed as D  # noqa: E402
 
 sys.path.insert(0, str(GOLDEN))
 import make_golden  # noqa: E402
@@ -235,7 +236,7 @@ def test_interleaved_row_blocks_tile_the_pair_space(oracle):
                         for part in range(parts):
                             sel.set_row_interleave(block, parts, part)
                             res = sel.run(cfg.tau, mode, r, b, algo=algo)
-                            assert (((res["i"] // block) % parts) == part).all()
+                            assert (D.interleave_owner(res["i"], block, parts) == part).all()      # (blocks are dealt boustrophedon)
                             got.append(res)
                             ev += sel.stats()["evaluated"]
                         sel.set_row_interleave(0, 1, 0)
