@@ -239,7 +239,21 @@ void hll_union_hist_bs_kernel(const uint32_t* __restrict__ bs, const uint8_t* __
     if (n_pairs > cap) n_pairs = cap;
     n_pairs = n_pairs > chunk_off ? min(n_pairs - chunk_off, chunk_len) : 0;
     pairs += chunk_off;
-    const u64 stride = (u64)(gridDim.x >> 3) * kWavesPerBlock;            // waves per XCD (the host launches a multiple of 8 blocks)
+    // A SHORT list runs on part of the grid: the device holds 1 024 SIMDs x (4 or 2) waves of this kernel at a time, and a wave's first
+    // pair costs three dependent round trips (count, pair record, rows) before any arithmetic.  With 8 192 waves for 16 000 pairs (one of
+    // 8 ranks of the weak-scaled workload) every wave took two pairs and half of the waves could only start when the first half had
+    // ended: 44 us for 16 us of arithmetic.  Up to eight pairs per resident wave the list is therefore dealt to at most ONE round of
+    // waves (the other blocks leave at once); longer lists keep the whole grid, whose two rounds of shorter waves end more evenly.
+    u64 blocks_active = gridDim.x;
+    {
+        const u64 resident = 1024ull * (NB <= 5 ? 4 : 2);
+        if (n_pairs <= 8 * resident) {
+            const u64 waves = min(resident, max(n_pairs, (u64)64));
+            blocks_active = min((u64)gridDim.x, ((waves + 8 * kWavesPerBlock - 1) / (8 * kWavesPerBlock)) * 8);
+        }
+    }
+    if (blockIdx.x >= blocks_active) return;
+    const u64 stride = (blocks_active >> 3) * kWavesPerBlock;             // waves per XCD (the host launches a multiple of 8 blocks)
     const int my_bin = ((lane & 2) ? 32 : 0) + 2 * bs_pidx(lane) + (lane & 1);
     // A DENSE survivor graph (n_pairs >= dense_pairs; the host sets 32 pairs per query row of the pass on a grouped list, "hist_dense_degree"): a query
     // row has tens to hundreds of partners spread over the whole table, the table does not fit one L2 (4 MiB = ~400 rows) and in list
@@ -249,9 +263,13 @@ void hll_union_hist_bs_kernel(const uint32_t* __restrict__ bs, const uint8_t* __
     // which all its waves pass through together (the list is query-major).  Same counts in the same slots either way.
     const bool dense = n_pairs >= dense_pairs;
     const uint32_t xcd = blockIdx.x & 7u;
-    // a short list is dealt out pair by pair: runs only pay (the query row stays in registers) once every wave has several of them --
-    // one of 8 ranks of cfg4, 28 000 pairs on 8 192 waves: 49.9 us with single pairs, 58.3 us with runs of 4
-    run_len = dense ? kWave : (int)max((u64)1, min((u64)min(run_len, kWave), n_pairs / (16 * stride)));
+    // Runs only pay (the query row stays in registers) once every wave has several of them: on the whole grid a list is dealt out in
+    // runs of n_pairs / 16 per wave at most (one of 8 ranks of cfg4, 56 000 pairs on 8 192 waves: 49.9 us with single pairs, 58.3 us with
+    // runs of 4).  A short list on its one round of waves gives every wave ONE run of its n_pairs / waves consecutive pairs: with single
+    // pairs every pair fetched both of its rows (one of 8 ranks at 28 280 genomes: 16 000 pairs, 41 us for 16 us of arithmetic).
+    const u64 waves_active = 8 * stride;
+    const u64 per_wave = blocks_active < gridDim.x ? (n_pairs + waves_active - 1) / waves_active : n_pairs / (16 * stride);
+    run_len = dense ? kWave : (int)max((u64)1, min((u64)min(run_len, kWave), per_wave));
     const u64 n_tasks = (n_pairs + run_len - 1) / run_len;
     const u64 tasks_per_xcd = dense ? n_tasks : (n_tasks + 7) >> 3;
     const u64 t_begin = dense ? 0 : (u64)xcd * tasks_per_xcd, t_end = min(t_begin + tasks_per_xcd, n_tasks);

@@ -14,6 +14,8 @@ cfg = base.scaled(n)
 hll, aux, cards, _, _ = pkg.synth_device(cfg)
 r, b = pkg.banding(cfg.m, cfg.tau)
 sel = pkg.Selector(0); sel.attach(hll, aux, cards)
+for kv in sys.argv[2:]:                                   # name=value ... -> selhip_ctx_set_param
+    name, _, val = kv.partition("="); sel.set_param(name, int(val)); print("param", name, val)
 def brk(rows, label):
     for _ in range(3): sel.run(cfg.tau, pkg.MODE_SMH, r, b, rows=rows, fetch=False)
     sel.timing(1)
