@@ -183,8 +183,10 @@ int check_device(std::string* err) {
     return SELHIP_OK;
 }
 
-// timing level 1: every scope; level 2: only the dominant stage-1 kernel (an event pair costs ~10 us of stream time, and a
-// pass of the default workload is ~0.4 ms)
+// timing level 1: every scope; level 2: only the dominant kernel of the pass (an event pair costs ~5 us of stream time, and a pass of
+// the default workload is 0.24 ms).  Handing the pair to the launch itself (hipExtLaunchKernelGGL: the dispatch's own start / end
+// timestamps) was built and measured in round 3: same step (0.2427 / 0.2404 against 0.2399 / 0.2414 ms), same kernel figure
+// (103.9 against 103.3 us) -- the runtime brackets the dispatch with the same packets either way (gpurun_out/r03/t_*).  Not kept.
 struct TimerScope {
     selhip_ctx* c; int id; hipStream_t st; hipEvent_t a = nullptr, b = nullptr; bool on;
     TimerScope(selhip_ctx* c_, int id_) : TimerScope(c_, id_, c_->stream) {}
