@@ -57,7 +57,9 @@ CYC_VALU_RAW = 2.0             # MI355X_MICROARCH.md: a wave64 VALU instruction 
 CYC_MIX_MEASURED = 3.85        # profiles/r02_valu_rate.txt, rows "mix: v_xor_b32 (VGPR) / v_pk_min_u16": 3.76-3.95 cycles per instruction
 CYC_BITOP3 = 2.2               # profiles/r03_bitplane_rate.txt: v_bitop3_b32 2.17-2.27 cycles (it pairs like a VGPR-only VOP2); v_bcnt_u32_b32 4.05
 CYC_DS_2DWORD = 4.0            # MI355X_MICROARCH.md LDS table: a DS op moving 2 dwords per lane (ds_add_u32, ds_write_b32) = 4 cycles/CU
-IL_BLOCK = 128                 # rows per interleave block of the multi-GPU partition
+IL_BLOCK = 128                 # rows per interleave block of the multi-GPU partition.  (256 rows -- the candidates of a join block -- were measured
+                               # in round 3: the slowest of 2 / 4 / 8 ranks of the weak-scaled workload 2 % faster, configs[3] x 8 the same, configs[4] x 8
+                               # 15 % SLOWER (1.52 against 1.32 ms: 128-row join tiles want one tile per block): scripts/il_block_parts.py, emulate_strong.py --block=)
 
 
 def parse():

@@ -268,8 +268,12 @@ void hll_union_hist_bs_kernel(const uint32_t* __restrict__ bs, const uint8_t* __
     // runs of 4).  A short list on its one round of waves gives every wave ONE run of its n_pairs / waves consecutive pairs: with single
     // pairs every pair fetched both of its rows (one of 8 ranks at 28 280 genomes: 16 000 pairs, 41 us for 16 us of arithmetic).
     const u64 waves_active = 8 * stride;
-    const u64 per_wave = blocks_active < gridDim.x ? (n_pairs + waves_active - 1) / waves_active : n_pairs / (16 * stride);
-    run_len = dense ? kWave : (int)max((u64)1, min((u64)min(run_len, kWave), per_wave));
+    // (runs of at most 2 there: longer ones put the uses of a candidate row at different points of different waves' serial chains
+    //  and it leaves L2 in between -- one chunk lane of a rank of cfg4, 28 000 pairs, table 512 MB: 47.3 / 49.2 / 56.3 us with runs of
+    //  1 / 2 / 4; the 16 000-pair share above: 40.1 / 37.1 / 37.3)
+    const bool short_list = blocks_active < gridDim.x;
+    const u64 per_wave = short_list ? (n_pairs + waves_active - 1) / waves_active : n_pairs / (16 * stride);
+    run_len = dense ? kWave : (int)max((u64)1, min((u64)min(run_len, short_list ? 2 : kWave), per_wave));
     const u64 n_tasks = (n_pairs + run_len - 1) / run_len;
     const u64 tasks_per_xcd = dense ? n_tasks : (n_tasks + 7) >> 3;
     const u64 t_begin = dense ? 0 : (u64)xcd * tasks_per_xcd, t_end = min(t_begin + tasks_per_xcd, n_tasks);

@@ -18,6 +18,9 @@ sel = pkg.Selector(0); sel.attach(hll, aux, cards)
 if cfg.p_aux:
     sel.attach_aux_hll(ah, cfg.p_aux); sel.set_criterion(pkg.CRIT_HLL_A_SMH_A)
 n = cfg.n_genomes
+IL_BLOCK = 128
+for f in flags:
+    if f.startswith("--block="): IL_BLOCK = int(f.split("=")[1]); print(wl, "interleave block", IL_BLOCK, flush=True)
 if "--sig-cache" in flags:
     sel.set_param("sig_cache", 1)          # every rank of a strong-scaled job runs many passes over the same replica: signatures built once
     print(wl, "signature cache ON (selhip_ctx_set_param sig_cache=1)", flush=True)
@@ -38,13 +41,13 @@ print(wl, "1 rank: %.3f ms" % (one * 1e3), flush=True)
 for world in worlds:
     worst = 0
     for part in range(world):
-        sel.set_row_interleave(128, world, part)
+        sel.set_row_interleave(IL_BLOCK, world, part)
         worst = max(worst, timeit())
     sel.set_row_interleave(0, 1, 0)
     print(wl, "world %d: slowest rank %.3f ms -> speed-up %.2f (efficiency %.0f %%)" % (world, worst * 1e3, one / worst, 100 * one / worst / world), flush=True)
 # kernel breakdown of one rank's share at the largest world size
 world = worlds[-1]
-sel.set_row_interleave(128, world, world // 2)
+sel.set_row_interleave(IL_BLOCK, world, world // 2)
 for _ in range(2): sel.run(cfg.tau, pkg.MODE_SMH, r, b, fetch=False)
 sel.timing(1)
 for _ in range(5): sel.run(cfg.tau, pkg.MODE_SMH, r, b, fetch=False)
