@@ -389,6 +389,13 @@ void frame_results_kernel(const selhip_pair_t* __restrict__ results, const u64* 
 }
 
 // ---------------------------------------------------------------------------------------------
+// (Round 3 built stage 2a + 2b as ONE kernel -- a block takes 64 consecutive pairs, its four waves build 16 histograms each into an LDS
+// tile, wave 0 runs the estimator and appends; a dense list falls back to stage 2a's slice walk and a device word tells the select kernel
+// behind it whether anything is left -- bit-identical in the parity suite, and slower everywhere: cfg3 77 + 7 us (the select launch that
+// finds nothing to do) against 52 + 20, cfg4 0.425 + 0.13 against 0.289 + 0.144 ms, configs[1] 43 against 12 + 18 us
+// (gpurun_out/r03/x_*).  Whole batches per block cannot be dealt as evenly as stage 2a's one- and two-pair tasks (703 blocks on 1 024
+// slots: 2.75 waves per SIMD), and the solve's latency then sits behind the slowest block's sixteen pairs instead of behind the last
+// pair.  Not kept.)
 // ertl_select_kernel: one LANE per histogram.  The 64 histograms of a wave are staged in LDS
 // (pitch 65 -> conflict-free) because the estimator indexes them with run-time k.
 //   MODE 0: est[j] = estimate                                     (selhip_ertl_estimate, cards)
