@@ -109,8 +109,8 @@ void small_pass_kernel(const u64* __restrict__ aux, const double* __restrict__ c
 
     // ---- phase 1: the block's (up to kSmallRows) query rows against every candidate.  Rows are dealt to the blocks boustrophedon
     // (row slot j G + b for even j, j G + G-1-b for odd j), so every block meets about the same number of candidates although row i only
-    // has n-1-i of them.  The rows' signatures sit in LDS; kSmallChunks x 256 candidates read eight bands of their band-major signatures at
-    // a time (32 coalesced loads in flight per lane: the loads' round trips, not their bytes, are what this phase costs) and meet all the
+    // has n-1-i of them.  The rows' signatures sit in LDS; kSmallChunks x 256 candidates read kSmallBands bands of their band-major signatures at
+    // a time (64 coalesced loads in flight per lane: the loads' round trips, not their bytes, are what this phase costs) and meet all the
     // rows; per row a lane keeps the first band whose 32-bit signatures agree and queues (row, band, candidate) in LDS.  The queue is
     // then verified sixteen lanes to a candidate: the flagged band alone is compared on the full sketches, one bucket per lane, so a
     // block's few dozen candidates cost ONE round trip.  The literal lane-serial smh_a only decides after a 32-bit collision, as in
