@@ -12,7 +12,7 @@
 //   -t <n>      host threads for loading sketches (selection.cpp:97)
 //   -g <n>      number of GPUs to shard the pair space over (default 1; any criterion); selected pairs gathered over RCCL/xGMI
 //   -n          no CB pruning ("smh_a" mode of experiments/src/time_smh.cpp:229-257)
-//   -A <algo>   stage-1 algorithm: auto | stream | sig
+//   -A <algo>   stage-1 algorithm: auto | stream | sig | hashjoin (sort-based: same result, sub-quadratic)
 //   -F <0|1>    estimator flavour: 1 = FMA (reference Makefile build on FMA hosts, default), 0 = strict
 //   -B <n>      out-of-core: keep the sketches in host memory and process the pair space in blocks of n genomes
 //               (selhip_ooc_select; same output); 0 = everything resident on the device (default)
@@ -55,7 +55,7 @@ int main(int argc, char* argv[]) {
             case 't': threads = std::stoi(optarg); break;
             case 'g': n_gpus = std::stoi(optarg); break;
             case 'n': mode = SELHIP_MODE_SMH; break;
-            case 'A': algo = !strcmp(optarg, "stream") ? SELHIP_ALGO_STREAM : !strcmp(optarg, "sig") ? SELHIP_ALGO_SIG : SELHIP_ALGO_AUTO; break;
+            case 'A': algo = !strcmp(optarg, "stream") ? SELHIP_ALGO_STREAM : !strcmp(optarg, "sig") ? SELHIP_ALGO_SIG : !strcmp(optarg, "hashjoin") ? SELHIP_ALGO_HASHJOIN : SELHIP_ALGO_AUTO; break;
             case 'F': fp_mode = std::stoi(optarg) ? SELHIP_FP_FMA : SELHIP_FP_STRICT; break;
             default: break;
         }

@@ -33,6 +33,14 @@ def test_selection_cli_matches_reference_stdout(a, h):
     if h == "0.9":
         want = (GOLDEN / "results_reference.txt").read_text().replace("datasets/test_influenzaA/", "influenza/")
         assert out.stdout == want
+    # the stage-1 algorithms are interchangeable: -A stream / sig / hashjoin (sort-based) print the same lines
+    for algo in ("stream", "sig", "hashjoin"):
+        alt = subprocess.run([str(BIN / "selection"), "-l", "influenza_filelist.txt", "-h", h, "-a", str(a), "-b", "128", "-F", "0", "-A", algo],
+                             cwd=GOLDEN, capture_output=True, text=True)
+        if algo == "sig" and alt.returncode != 0:                # (an explicit -A sig refuses band shapes the signature join does not cover)
+            assert "ALGO_SIG needs" in alt.stderr
+            continue
+        assert alt.returncode == 0 and alt.stdout == out.stdout, (algo, alt.stderr)
 
 
 @pytest.mark.gpu
